@@ -1,0 +1,42 @@
+"""Parity cases shared by the fixture generator and the tests (data only).
+
+Each case names a model configuration (the reference's config keys), a batch/size and the
+two seeds from which handmvnet_amd.synth regenerates weights and inputs bit-exactly.
+"""
+from __future__ import annotations
+
+ALL_POS = ["pos2d", "crop", "sin"]
+
+CASES = {
+    # tiny end-to-end cases (SURVEY.md section 8(c) fixture plan)
+    "tiny_r50":     dict(bt="50_paper", ch=[1024], V=2, B=1, size=64, pos=ALL_POS, gcn=True, wseed=1, iseed=11),
+    "tiny_r18":     dict(bt="18", ch=[256, 128, 64], V=2, B=1, size=64, pos=ALL_POS, gcn=True, wseed=2, iseed=12),
+    # BASELINE.json configs[0]: HO3D yaml, 4 selected views, 128x128, batch 1
+    "cfg1_r50_v4_128": dict(bt="50_paper", ch=[1024], V=4, B=1, size=128, pos=ALL_POS, gcn=True, wseed=3, iseed=13),
+    # configs[1]-shaped: r18, 4 views, 256x256 (batch 2 instead of 8 to keep the CPU suite short)
+    "cfg2s_r18_v4_256": dict(bt="18", ch=[256, 128, 64], V=4, B=2, size=256, pos=ALL_POS, gcn=True, wseed=4, iseed=14),
+    # configs[2]-shaped: r50-paper, 8 views, 256x256 (batch 2 instead of 32)
+    "cfg3s_r50_v8_256": dict(bt="50_paper", ch=[1024], V=8, B=2, size=256, pos=ALL_POS, gcn=True, wseed=5, iseed=15),
+    # *_wo_cam release configs: no crop FoV columns; NN decoder variant
+    "r50_wocam_nn": dict(bt="50_paper", ch=[1024], V=3, B=1, size=64, pos=["pos2d", "sin"], gcn=False, wseed=6, iseed=16),
+    # frozen BN, no sinusoidal PE, 3 fusion layers
+    "r18_frozen_nosin": dict(bt="18", ch=[256, 128, 64], V=2, B=2, size=64, pos=["pos2d", "crop"], gcn=True, wseed=7,
+                             iseed=17, freeze_bn=True, fusion_layers=3),
+    # ResNet-34, single sampled level
+    "r34_onelevel": dict(bt="34", ch=[256], V=2, B=1, size=64, pos=ALL_POS, gcn=True, wseed=8, iseed=18),
+    # non-power-of-two input, config constants that differ from the tensor shapes (handmvnet.py:252 quirk)
+    "r50_odd_96": dict(bt="50_paper", ch=[1024], V=5, B=1, size=96, pos=ALL_POS, gcn=True, wseed=9, iseed=19,
+                       image_size=200, heatmap_size=32),
+}
+
+
+def case_params(spec: dict):
+    """The three dicts the reference constructor takes (handmvnet.py:28)."""
+    tp = {"debug": False, "root_relative": True}
+    mp = {"num_views": spec["V"], "backbone": "resnet", "backbone_type": spec["bt"],
+          "backbone_channels": list(spec["ch"]), "backbone_pretrained": False, "backbone_early_return": 3,
+          "freeze_bn": bool(spec.get("freeze_bn", False)), "pos_enc": list(spec["pos"]), "fusion": "cross_attn",
+          "fusion_layers": int(spec.get("fusion_layers", 5)), "use_gcn": bool(spec["gcn"])}
+    dp = {"batch_size": spec["B"], "image_size": int(spec.get("image_size", spec["size"])),
+          "heatmap_size": int(spec.get("heatmap_size", spec["size"] // 8)), "name": "ho3d"}
+    return tp, mp, dp

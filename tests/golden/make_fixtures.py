@@ -1,0 +1,125 @@
+"""Generate the golden fixtures from the REAL reference (run in the build container only).
+
+    python tests/golden/make_fixtures.py            # writes tests/golden/<case>.npz
+
+For every case in cases.py this script
+  1. builds the three reference config dicts, synthesises weights with
+     handmvnet_amd.synth (portable, seed-keyed) and loads them with strict=True into the
+     reference's HandMvNet (imported from /root/reference via ref_harness.py),
+  2. runs the reference forward on synthesised inputs,
+  3. stores the reference outputs plus sampled stage tensors as a small .npz.
+
+The .npz files are data only (inputs are regenerated from seeds; weights likewise).
+The GPU box has no /root/reference: tests read the committed .npz files.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import torch  # noqa: E402
+
+import ref_harness  # noqa: E402
+from cases import CASES, case_params  # noqa: E402
+from handmvnet_amd.spec import config_from_params  # noqa: E402
+from handmvnet_amd.synth import synth_inputs, synth_state_dict  # noqa: E402
+
+N_SAMPLE = 2048
+
+
+def sample_idx(name: str, n: int) -> np.ndarray:
+    if n <= N_SAMPLE:
+        return np.arange(n, dtype=np.int64)
+    import zlib
+    rng = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode())))
+    return np.sort(rng.choice(n, N_SAMPLE, replace=False)).astype(np.int64)
+
+
+def run_case(name: str, spec: dict, check_oracle: bool = True) -> dict:
+    tp, mp, dp = case_params(spec)
+    cfg = config_from_params(tp, mp, dp)
+    sd = synth_state_dict(cfg, spec["wseed"])
+    model = ref_harness.build_reference_model(tp, mp, dp, sd)
+    x, bbox, intr = synth_inputs(cfg, spec["B"], spec["iseed"], spec["size"])
+
+    import models.handmvnet as ref_mod  # the reference module object
+    stages = {}
+    orig_sa = ref_mod.soft_argmax_2d
+
+    def sa(hm, *a, **k):
+        out = orig_sa(hm, *a, **k)
+        stages["coords_hm"] = out.detach().clone()
+        return out
+
+    ref_mod.soft_argmax_2d = sa
+    hooks = [
+        model.backbone.register_forward_hook(lambda m, i, o: stages.__setitem__(
+            "feat0", (list(reversed([v for v in o.values() if v.dim() == 4]))[0] if isinstance(o, dict) else o).detach().clone())),
+        model.joints_late_fusion.register_forward_pre_hook(lambda m, i: stages.__setitem__("tokens", i[0].detach().clone())),
+        model.joints_late_fusion.register_forward_hook(lambda m, i, o: stages.__setitem__("fused", o.detach().clone())),
+    ]
+    try:
+        t0 = time.time()
+        with torch.no_grad():
+            out = model(torch.from_numpy(x), torch.from_numpy(bbox), {"intrinsic": torch.from_numpy(intr)})
+        dt = time.time() - t0
+    finally:
+        ref_mod.soft_argmax_2d = orig_sa
+        for h in hooks:
+            h.remove()
+    hm = out["heatmap"].reshape(-1, out["heatmap"].shape[-1] * out["heatmap"].shape[-2])
+    top2 = hm.topk(2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1]).numpy()
+    fx = {
+        "spec": np.array(json.dumps(spec)),
+        "joints_cam": out["joints_cam"].numpy(),
+        "joints_crop_img": out["joints_crop_img"].numpy(),
+        "coords_hm": stages["coords_hm"].numpy(),
+        "hm_gap_quantiles": np.quantile(gap, [0.0, 0.01, 0.1, 0.5]).astype(np.float32),
+        "ref_seconds": np.float32(dt),
+    }
+    for nm, t in (("heatmap", out["heatmap"]), ("feat0", stages["feat0"]), ("tokens", stages["tokens"]),
+                  ("fused", stages["fused"])):
+        flat = t.numpy().reshape(-1)
+        idx = sample_idx(name + nm, flat.size)
+        fx[nm + "_idx"] = idx
+        fx[nm + "_val"] = flat[idx].copy()
+        fx[nm + "_shape"] = np.array(t.shape, dtype=np.int64)
+        fx[nm + "_sum"] = np.float64(flat.astype(np.float64).sum())
+        fx[nm + "_sqsum"] = np.float64((flat.astype(np.float64) ** 2).sum())
+    if check_oracle:
+        from oracle.oracle import Oracle
+        for acc in ("f32", "f64"):
+            o = Oracle(cfg, sd, acc).forward(x, bbox, intr, stages=True)
+            rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+            print(f"  oracle[{acc}] vs reference: joints_cam rel-L2 {rel(o['joints_cam'], fx['joints_cam']):.3e}  "
+                  f"coords max|d| {np.abs(o['coords_hm'] - fx['coords_hm']).max():.3e}  "
+                  f"heatmap rel {rel(o['heatmap'], out['heatmap'].numpy()):.3e}  "
+                  f"feat0 rel {rel(o['feat0'], stages['feat0'].numpy()):.3e}  "
+                  f"tokens rel {rel(o['tokens'], stages['tokens'].numpy()):.3e}  "
+                  f"fused rel {rel(o['fused'], stages['fused'].numpy()):.3e}")
+    print(f"{name}: reference {dt:.2f}s  hm gap q0/q1/q10/q50 = {fx['hm_gap_quantiles']}")
+    return fx
+
+
+def main(argv):
+    only = set(argv[1:])
+    for name, spec in CASES.items():
+        if only and name not in only:
+            continue
+        fx = run_case(name, spec)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    main(sys.argv)

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the HandMvNet hot path on MI355X (the eval_fps.py protocol,
+/root/reference/src/eval_fps.py:68-108, re-stated: synthetic frames resident on the device,
+warm-up, K timed forwards, frames/s = K*B*V / t -- without eval_fps's uninitialised
+intrinsics, its hard-coded 8 views and the CPU MANO step).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload = BASELINE.json configs[2] (the configuration the metric is quoted on): B=32
+multi-view samples x V=8 views of 256x256 per GPU, ResNet50-paper backbone, cross-attention
+fusion (5 layers), GCN decoder, fp32 on the fp32 matrix cores.  N GPUs = N independent
+shards of 32 samples (weak scaling) + one RCCL all-gather of the results.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from handmvnet_amd import HandMvNet  # noqa: E402
+from handmvnet_amd.dist import gather_outputs  # noqa: E402
+from handmvnet_amd.spec import config_from_params, conv_flops_per_image  # noqa: E402
+from handmvnet_amd.synth import synth_inputs, synth_state_dict  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+WORKLOADS = {
+    # name: (backbone_type, channels, V, B per GPU, size)
+    "cfg3": ("50_paper", [1024], 8, 32, 256),      # BASELINE.json configs[2]
+    "cfg2": ("18", [256, 128, 64], 4, 8, 256),     # BASELINE.json configs[1]
+}
+
+
+def params(bt, ch, V, B, size):
+    tp = {"debug": False, "root_relative": True}
+    mp = {"num_views": V, "backbone": "resnet", "backbone_type": bt, "backbone_channels": ch, "backbone_pretrained": False,
+          "backbone_early_return": 3, "pos_enc": ["pos2d", "crop", "sin"], "fusion": "cross_attn", "fusion_layers": 5,
+          "use_gcn": True}
+    dp = {"batch_size": B, "image_size": size, "heatmap_size": size // 8, "name": "dexycb"}
+    return tp, mp, dp
+
+
+def forward_flops(cfg, B, size):
+    """Dense algorithmic FLOPs of one forward (SURVEY.md section 8(d) convention)."""
+    f = conv_flops_per_image(cfg, size)
+    per_frame = sum(f.values())
+    V, d, T = cfg.num_views, cfg.feat_dim, cfg.num_views * 21
+    def block(tq, tk):
+        proj = 2 * d * 1024 * (tq + 2 * tk) + 2 * 1024 * d * tq
+        att = 2 * 2 * tq * tk * 128 * 8
+        ff = 2 * 2 * d * 128 * tq
+        return proj + att + ff
+    half = (cfg.fusion_layers - 1) // 2
+    fusion = half * block(T, T) + block(21, T - 21) + half * block(21, 21)
+    dec = 2 * 21 * 3 * (d * 256 + 256 * 64 + 64 * 3)
+    return B * (V * per_frame + fusion + dec)
+
+
+def cpu_baseline(cfg, sd, size, model, dev, min_seconds=10.0):
+    """The CPU oracle (fp32 port of the reference, OpenMP over the host cores) timed on a
+    bounded sample of the same workload; also re-checks GPU-vs-oracle parity on it."""
+    from oracle.oracle import Oracle
+    orc = Oracle(cfg, sd, "f32")
+    x, bbox, intr = synth_inputs(cfg, 1, 4242, size)
+    ref = orc.forward(x, bbox, intr)                      # warm-up + parity reference
+    t0, n = time.perf_counter(), 0
+    while True:
+        orc.forward(x, bbox, intr)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= min_seconds or n >= 50:
+            break
+    out = model(torch.from_numpy(x).to(dev), torch.from_numpy(bbox).to(dev), {"intrinsic": torch.from_numpy(intr).to(dev)})
+    torch.cuda.synchronize()
+    got = out["joints_cam"].cpu().numpy()
+    rel = float(np.linalg.norm(got - ref["joints_cam"]) / np.linalg.norm(ref["joints_cam"]))
+    frames = n * cfg.num_views
+    return {"value": round(frames / el, 3), "unit": "frames/s", "cores": orc.num_threads, "kind": "port",
+            "sample": f"{n} forwards of B=1 x V={cfg.num_views} x {size}x{size} ({frames} frames, {el:.1f} s) "
+                      f"through oracle/hmv_oracle.c (fp32, OpenMP)"}, rel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override samples per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    bt, ch, V, B, size = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    tp, mp, dp = params(bt, ch, V, B, size)
+    cfg = config_from_params(tp, mp, dp)
+    sd = synth_state_dict(cfg, 1)
+    model = HandMvNet(tp, mp, dp)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    model.freeze()
+
+    # synthetic frames of this rank's shard, resident in HBM before the timed region
+    x, bbox, intr = synth_inputs(cfg, B, 1000 + rank, size)
+    xt, bt_, it = torch.from_numpy(x).to(dev), torch.from_numpy(bbox).to(dev), torch.from_numpy(intr).to(dev)
+    cam = {"intrinsic": it}
+    model.reserve(B, size, size, dev)
+
+    def step():
+        out = model(xt, bt_, cam)
+        return gather_outputs(out) if world > 1 else out
+
+    for _ in range(args.warmup):
+        step()
+    model.set_profiling(True)          # hipEvent pairs around every conv/GEMM launch of the timed steps
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    recs = model.profile_records()
+    model.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel from the live per-launch event timings
+        fam = {}
+        for r in recs:
+            f = fam.setdefault(r["kernel"], {"ms": 0.0, "flops": 0.0, "n": 0})
+            f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["n"] += 1
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        d = fam[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": d["n"] // max(args.steps, 1), "avg_launch_ms": round(d["ms"] / d["n"], 4),
+                    "flops_per_launch": d["flops"] / d["n"]}
+        ms_step = elapsed / args.steps * 1e3
+        total_flops = forward_flops(cfg, B, size)
+        line = {
+            "metric": "samples/sec (BxV frames) eval_fps.py, 8-view 256x256; 21-kpt L2 vs reference",
+            "value": round(args.steps * B * V * world / elapsed, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{2 if args.workload == 'cfg3' else 1}]: B={B}/GPU x V={V} x {size}x{size}, "
+                                   f"resnet{bt} backbone, d={cfg.feat_dim}, cross_attn x{cfg.fusion_layers}, GCN decoder",
+                       "global_batch": B * world, "views": V, "frame": size, "parallelism": f"sample-shard x{world}"},
+            "roofline": roofline,
+            "forward": {"algorithmic_gflop": round(total_flops / 1e9, 1),
+                        "tflops": round(total_flops / (ms_step * 1e-3) / 1e12, 2),
+                        "frac_of_f32_mfma_peak": round(total_flops / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "kernels": {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                        for k, v in fam.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, rel = cpu_baseline(cfg, sd, size, model, dev, args.cpu_seconds)
+            line["cpu_baseline"] = cb
+            line["parity_rel_l2_vs_oracle"] = float(f"{rel:.3e}")
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

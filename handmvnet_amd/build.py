@@ -1,0 +1,56 @@
+"""Builds libhandmv.so (the HIP engine) in-tree with hipcc for gfx950.
+
+    python -m handmvnet_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting handmvnet_amd/libhandmv.so travels to the
+GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "libhandmv.so")
+SOURCES = ["conv_igemm.hip", "misc_kernels.hip", "engine.hip"]
+HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(os.path.dirname(HERE), "include", "handmv.h")]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or _stale(op, [sp] + HEADERS):
+            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd))
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+            if verbose and r.stderr.strip():
+                print(r.stderr)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

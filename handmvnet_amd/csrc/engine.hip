@@ -1,0 +1,929 @@
+// engine.hip -- host side of libhandmv.so: weight ingestion (BN folding, K-major repack),
+// workspace planning and the forward orchestration behind the C ABI of include/handmv.h.
+//
+// The forward mirrors HandMvNet.forward (/root/reference/src/models/handmvnet.py:158-266)
+// stage by stage, but NHWC end to end and with every conv/linear routed to the one
+// implicit-GEMM MFMA kernel family (conv_igemm.hip).  There is no CPU fallback: every
+// entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/handmv.h"
+#include "kernels.h"
+
+using namespace hmv;
+
+namespace {
+
+constexpr int NJ = 21, HEADS = 8, DHEAD = 128, INNER = HEADS * DHEAD;
+const int kBlocks[3][4] = {{2, 2, 2, 2}, {3, 4, 6, 3}, {3, 4, 6, 3}};
+
+std::string g_create_err;
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+// One GEMM-shaped layer on the device: Wt [Cout_pad][Kpad] + bias [Cout_pad].
+struct Layer {
+    float *w = nullptr, *bias = nullptr;
+    int Cin = 0, Cout = 0, R = 1, S = 1, K = 0, Kpad = 0, Cout_pad = 0;
+    std::string label;
+};
+
+struct Block {
+    Layer c1, c2, c3, ds;
+    bool has_ds = false;
+    int stride = 1;
+};
+
+struct AttnLayer {
+    Layer qkv, out, ff1, ff2;
+    float *n1g = nullptr, *n1b = nullptr, *n2g = nullptr, *n2b = nullptr, *fg = nullptr, *fb = nullptr;
+};
+
+// First-fit planner over one contiguous arena.  Run once "dry" to size the workspace and
+// once for real; both runs issue the same alloc/free sequence so offsets agree.
+struct Arena {
+    struct Seg { size_t off, size; };
+    std::vector<Seg> free_list;  // sorted by offset
+    std::map<size_t, size_t> live;
+    size_t high = 0, top = 0;
+    char *base = nullptr;
+    void reset(char *b) { free_list.clear(); live.clear(); high = top = 0; base = b; }
+    float *alloc(size_t floats) {
+        size_t bytes = (floats * sizeof(float) + 255) / 256 * 256;
+        if (bytes == 0) bytes = 256;
+        for (size_t i = 0; i < free_list.size(); ++i) {
+            if (free_list[i].size >= bytes) {
+                size_t off = free_list[i].off;
+                if (free_list[i].size == bytes) free_list.erase(free_list.begin() + i);
+                else { free_list[i].off += bytes; free_list[i].size -= bytes; }
+                live[off] = bytes;
+                return reinterpret_cast<float *>(base + off);
+            }
+        }
+        size_t off = top;
+        top += bytes;
+        if (top > high) high = top;
+        live[off] = bytes;
+        return reinterpret_cast<float *>(base + off);
+    }
+    void release(float *p) {
+        if (!p) return;
+        size_t off = (size_t)(reinterpret_cast<char *>(p) - base);
+        auto it = live.find(off);
+        if (it == live.end()) return;
+        Seg s{off, it->second};
+        live.erase(it);
+        size_t i = 0;
+        while (i < free_list.size() && free_list[i].off < s.off) ++i;
+        free_list.insert(free_list.begin() + i, s);
+        // coalesce neighbours
+        if (i + 1 < free_list.size() && free_list[i].off + free_list[i].size == free_list[i + 1].off) {
+            free_list[i].size += free_list[i + 1].size;
+            free_list.erase(free_list.begin() + i + 1);
+        }
+        if (i > 0 && free_list[i - 1].off + free_list[i - 1].size == free_list[i].off) {
+            free_list[i - 1].size += free_list[i].size;
+            free_list.erase(free_list.begin() + i);
+            --i;
+        }
+        if (!free_list.empty() && free_list.back().off + free_list.back().size == top) {
+            top = free_list.back().off;
+            free_list.pop_back();
+        }
+    }
+};
+
+struct ProfRec {
+    const char *name;
+    std::string label;
+    double flops;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct hmv_engine {
+    hmv_config cfg{};
+    std::string err;
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    std::vector<void *> dev_allocs;
+
+    // derived shape facts
+    int d = 0, ldt = 0, fdim = 0;
+    bool paper = false;
+
+    Layer stem;
+    std::vector<Block> blocks[3];
+    Layer pose0, pose1, pose2;   // r50: pose0 (1x1 1024->512), pose1 (1x1 512->21); r18/34: pose1 (3x3 128->64), pose2 (3x3 64->21)
+    Layer deconv[4];             // r18/34 ConvTranspose2d as 4 sub-pixel 2x2 convs (phase a*2+b)
+    Layer sample[3];
+    std::vector<AttnLayer> attn;
+    Layer gcn[3];
+    float *gcn_bias[3] = {nullptr, nullptr, nullptr};
+    float *cheb_t = nullptr;
+    Layer fc1, fc2;
+    float *pe = nullptr;
+
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    int reserved_batch = 0;
+    Arena plan;
+
+    bool capture = false;
+    int cap_batch = 0;
+    float *cap_feat0 = nullptr, *cap_coords = nullptr, *cap_tokens = nullptr, *cap_fused = nullptr;
+    size_t cap_feat0_n = 0, cap_coords_n = 0, cap_tokens_n = 0, cap_fused_n = 0;
+
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    size_t prof_used = 0;
+
+    int fail(int code, const char *fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return (h)->fail(HMV_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+// ------------------------------------------------------------------ weight ingestion helpers
+struct Loader {
+    hmv_engine *h;
+    int rc = HMV_OK;
+
+    const HostTensor *get(const std::string &key, std::initializer_list<int64_t> shape) {
+        auto it = h->host.find(key);
+        if (it == h->host.end()) {
+            if (rc == HMV_OK) rc = h->fail(HMV_ERR_MISSING_TENSOR, "Missing key(s) in state_dict: \"%s\"", key.c_str());
+            return nullptr;
+        }
+        std::vector<int64_t> want(shape);
+        if (it->second.shape != want) {
+            if (rc == HMV_OK) {
+                std::string got, exp;
+                for (auto v : it->second.shape) got += std::to_string(v) + ",";
+                for (auto v : want) exp += std::to_string(v) + ",";
+                rc = h->fail(HMV_ERR_SHAPE, "size mismatch for %s: got [%s] expected [%s]", key.c_str(), got.c_str(), exp.c_str());
+            }
+            return nullptr;
+        }
+        return &it->second;
+    }
+
+    float *upload(const std::vector<float> &v) {
+        if (rc != HMV_OK) return nullptr;
+        float *p = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), v.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            rc = h->fail(HMV_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
+            return nullptr;
+        }
+        h->dev_allocs.push_back(p);
+        return p;
+    }
+
+    // BatchNorm (eval) folded to scale/shift in double: resnet.py:59-74
+    bool bn_fold(const std::string &prefix, int C, std::vector<double> &scale, std::vector<double> &shift) {
+        const HostTensor *g = get(prefix + ".weight", {C}), *b = get(prefix + ".bias", {C});
+        const HostTensor *rm = get(prefix + ".running_mean", {C}), *rv = get(prefix + ".running_var", {C});
+        if (!g || !b || !rm || !rv) return false;
+        scale.resize(C);
+        shift.resize(C);
+        for (int c = 0; c < C; ++c) {
+            scale[c] = (double)g->data[c] / std::sqrt((double)rv->data[c] + 1e-5);
+            shift[c] = (double)b->data[c] - (double)rm->data[c] * scale[c];
+        }
+        return true;
+    }
+
+    // Generic finish: `wt(o, k)` supplies the un-scaled weight for output o, packed index k.
+    template <typename F>
+    void finish(Layer &L, const std::string &label, int Cin, int Cout, int R, int S, int K, F wt,
+                const std::vector<double> *scale, const std::vector<double> *shift, const float *conv_bias) {
+        L.label = label;
+        L.Cin = Cin; L.Cout = Cout; L.R = R; L.S = S; L.K = K;
+        L.Kpad = round_up(K, 32);
+        L.Cout_pad = round_up(Cout, 128);
+        if (rc != HMV_OK) return;
+        std::vector<float> w((size_t)L.Cout_pad * L.Kpad, 0.f), b((size_t)L.Cout_pad, 0.f);
+        for (int o = 0; o < Cout; ++o) {
+            const double sc = scale ? (*scale)[o] : 1.0;
+            for (int k = 0; k < K; ++k) w[(size_t)o * L.Kpad + k] = (float)((double)wt(o, k) * sc);
+            double bb = shift ? (*shift)[o] : 0.0;
+            if (conv_bias) bb += (double)conv_bias[o] * sc;
+            b[o] = (float)bb;
+        }
+        L.w = upload(w);
+        L.bias = upload(b);
+    }
+
+    // nn.Conv2d weight OIHW (+ optional bias key) followed by an optional BN
+    void conv(Layer &L, const std::string &label, const std::string &wkey, const std::string &bkey, const std::string &bn,
+              int Cout, int Cin, int R, int S, int cin_pad = 0) {
+        const HostTensor *w = get(wkey, {Cout, Cin, R, S});
+        const HostTensor *cb = bkey.empty() ? nullptr : get(bkey, {Cout});
+        std::vector<double> sc, sh;
+        const bool has_bn = !bn.empty();
+        if (has_bn && !bn_fold(bn, Cout, sc, sh)) return;
+        if (!w || (!bkey.empty() && !cb)) return;
+        const int cp = cin_pad ? cin_pad : Cin;
+        const float *wd = w->data.data();
+        auto wt = [=](int o, int k) -> float {
+            const int c = k % cp, tap = k / cp;
+            if (c >= Cin) return 0.f;
+            return wd[(((size_t)o * Cin + c) * R + tap / S) * S + tap % S];
+        };
+        finish(L, label, cp, Cout, R, S, R * S * cp, wt, has_bn ? &sc : nullptr, has_bn ? &sh : nullptr,
+               cb ? cb->data.data() : nullptr);
+    }
+
+    // nn.Linear weight [out][in] (+ optional bias)
+    void linear(Layer &L, const std::string &label, const std::string &wkey, const std::string &bkey, int out, int in) {
+        const HostTensor *w = get(wkey, {out, in});
+        const HostTensor *b = bkey.empty() ? nullptr : get(bkey, {out});
+        if (!w || (!bkey.empty() && !b)) return;
+        const float *wd = w->data.data();
+        auto wt = [=](int o, int k) -> float { return wd[(size_t)o * in + k]; };
+        finish(L, label, round_up(in, 32), out, 1, 1, in, wt, nullptr, nullptr, b ? b->data.data() : nullptr);
+    }
+
+    float *vec(const std::string &key, int n) {
+        const HostTensor *t = get(key, {n});
+        return t ? upload(t->data) : nullptr;
+    }
+};
+
+int backbone_level_channels(const hmv_config &c, int level /*0 = layer1*/) {
+    return (64 << level) * (c.backbone == HMV_RESNET50_PAPER ? 4 : 1);
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+const char *hmv_version(void) { return "handmv-mi355x 0.1 (gfx950, fp32 MFMA)"; }
+
+const char *hmv_last_error(hmv_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int hmv_create(const hmv_config *cfg, hmv_handle *out) {
+    auto bad = [&](const char *m) { g_create_err = m; return HMV_ERR_ARG; };
+    if (!cfg || !out) return bad("null argument");
+    if (cfg->struct_size != (int32_t)sizeof(hmv_config)) return bad("hmv_config.struct_size mismatch (ABI)");
+    if (cfg->backbone < HMV_RESNET18 || cfg->backbone > HMV_RESNET50_PAPER) return bad("Supports only 18, 34, 50_paper");
+    if (cfg->num_views < 1 || cfg->num_views > 12) return bad("num_views must be in [1, 12]");
+    if (cfg->fusion_layers < 1 || cfg->fusion_layers % 2 != 1) return bad("num_layers must be an odd number");
+    if (cfg->dtype != HMV_F32) { g_create_err = "only HMV_F32 is built"; return HMV_ERR_UNSUPPORTED; }
+    if (cfg->height < 32 || cfg->width < 32 || cfg->height % 32 || cfg->width % 32)
+        return bad("frame height/width must be positive multiples of 32");
+    if (cfg->image_size <= 0 || cfg->heatmap_size <= 0) return bad("image_size / heatmap_size must be positive");
+    const bool paper = cfg->backbone == HMV_RESNET50_PAPER;
+    if (cfg->n_levels < 1 || cfg->n_levels > (paper ? 1 : 3)) return bad("backbone_channels has too many levels for this backbone");
+    for (int i = 0; i < cfg->n_levels; ++i)
+        if (cfg->channels[i] != backbone_level_channels(*cfg, 2 - i)) return bad("backbone_channels do not match the backbone");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_err = "no HIP device: libhandmv has no CPU fallback";
+        return HMV_ERR_HIP;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) return bad("device ordinal out of range");
+    hmv_engine *h = new hmv_engine();
+    h->cfg = *cfg;
+    h->paper = paper;
+    h->fdim = 0;
+    for (int i = 0; i < cfg->n_levels; ++i) h->fdim += cfg->channels[i] / 2;
+    h->d = h->fdim + ((cfg->pos_enc & HMV_POS2D) ? 2 : 0) + ((cfg->pos_enc & HMV_POS_CROP) ? 10 : 0);
+    h->ldt = round_up(h->d, 32);
+    *out = h;
+    return HMV_OK;
+}
+
+int hmv_set_tensor(hmv_handle h, const char *key, const float *host, const int64_t *shape, int32_t ndim) {
+    if (!h || !key || !host || ndim < 0 || ndim > 4) return h ? h->fail(HMV_ERR_ARG, "bad hmv_set_tensor argument") : HMV_ERR_ARG;
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(host, host + n);
+    h->host[key] = std::move(t);
+    h->finalized = false;
+    return HMV_OK;
+}
+
+int hmv_finalize_weights(hmv_handle h) {
+    if (!h) return HMV_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    for (void *p : h->dev_allocs) hipFree(p);
+    h->dev_allocs.clear();
+    for (auto &v : h->blocks) v.clear();
+    h->attn.clear();
+    Loader L{h};
+    const hmv_config &c = h->cfg;
+    const int exp = h->paper ? 4 : 1;
+
+    // ---- backbone: resnet.py:162-177, 189-203
+    L.conv(h->stem, "stem", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 7, 7, /*cin_pad=*/4);
+    int inpl = 64;
+    for (int li = 0; li < 3; ++li) {
+        const int planes = 64 << li;
+        int stride = li == 0 ? 1 : 2;
+        if (h->paper && li == 2) stride = 1;
+        for (int bi = 0; bi < kBlocks[c.backbone][li]; ++bi) {
+            Block b;
+            b.stride = bi == 0 ? stride : 1;
+            const std::string p = "backbone.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+            const std::string lab = "layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+            const int outc = planes * exp;
+            if (h->paper) {
+                L.conv(b.c1, lab + ".conv1", p + ".conv1.weight", "", p + ".bn1", planes, inpl, 1, 1);
+                L.conv(b.c2, lab + ".conv2", p + ".conv2.weight", "", p + ".bn2", planes, planes, 3, 3);
+                L.conv(b.c3, lab + ".conv3", p + ".conv3.weight", "", p + ".bn3", outc, planes, 1, 1);
+            } else {
+                L.conv(b.c1, lab + ".conv1", p + ".conv1.weight", "", p + ".bn1", planes, inpl, 3, 3);
+                L.conv(b.c2, lab + ".conv2", p + ".conv2.weight", "", p + ".bn2", planes, planes, 3, 3);
+            }
+            b.has_ds = (b.stride != 1 || inpl != outc);
+            if (b.has_ds) L.conv(b.ds, lab + ".downsample", p + ".downsample.0.weight", "", p + ".downsample.1", outc, inpl, 1, 1);
+            inpl = outc;
+            h->blocks[li].push_back(b);
+        }
+    }
+    // ---- pose_net: handmvnet.py:70-86
+    const int c0 = c.channels[0];
+    if (h->paper) {
+        L.conv(h->pose0, "pose_net.0", "pose_net.0.weight", "pose_net.0.bias", "pose_net.1", 512, c0, 1, 1);
+        L.conv(h->pose1, "pose_net.3", "pose_net.3.weight", "pose_net.3.bias", "", NJ, 512, 1, 1);
+    } else {
+        // ConvTranspose2d(k4,s2,p1) weight [Cin][Cout][4][4] as 4 sub-pixel 2x2 convs:
+        // out[2q+a] takes ky = {3,1} (a=0, window starts at q-1) or {2,0} (a=1, window starts at q)
+        const HostTensor *w = L.get("pose_net.0.weight", {c0, 128, 4, 4});
+        const HostTensor *cb = L.get("pose_net.0.bias", {128});
+        std::vector<double> sc, sh;
+        const bool ok = L.bn_fold("pose_net.1", 128, sc, sh);
+        if (w && cb && ok) {
+            static const int kmap[2][2] = {{3, 1}, {2, 0}};
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    const float *wd = w->data.data();
+                    auto wt = [=](int o, int k) -> float {
+                        const int ci = k % c0, tap = k / c0, r = tap / 2, s = tap % 2;
+                        return wd[(((size_t)ci * 128 + o) * 4 + kmap[a][r]) * 4 + kmap[b][s]];
+                    };
+                    L.finish(h->deconv[a * 2 + b], "pose_net.0.phase" + std::to_string(a * 2 + b), c0, 128, 2, 2, 4 * c0, wt,
+                             &sc, &sh, cb->data.data());
+                }
+        }
+        L.conv(h->pose1, "pose_net.3", "pose_net.3.weight", "pose_net.3.bias", "pose_net.4", 64, 128, 3, 3);
+        L.conv(h->pose2, "pose_net.6", "pose_net.6.weight", "pose_net.6.bias", "", NJ, 64, 3, 3);
+    }
+    // ---- sample nets: nets.py:24-31
+    for (int i = 0; i < c.n_levels; ++i) {
+        const std::string p = "sample_nets." + std::to_string(i) + ".conv";
+        L.conv(h->sample[i], "sample_nets." + std::to_string(i), p + ".0.weight", p + ".0.bias", p + ".1", c.channels[i] / 2,
+               c.channels[i], 1, 1);
+    }
+    // ---- fusion: layers.py:177-200
+    const int d = h->d;
+    for (int l = 0; l < c.fusion_layers; ++l) {
+        AttnLayer a;
+        const std::string p = "joints_late_fusion.attn_fusion." + std::to_string(l);
+        const std::string lab = "fusion." + std::to_string(l);
+        const HostTensor *wq = L.get(p + ".to_q.weight", {INNER, d}), *wk = L.get(p + ".to_k.weight", {INNER, d}),
+                         *wv = L.get(p + ".to_v.weight", {INNER, d});
+        if (wq && wk && wv) {
+            const float *q = wq->data.data(), *k = wk->data.data(), *v = wv->data.data();
+            auto wt = [=](int o, int kk) -> float {
+                const float *src = o < INNER ? q : (o < 2 * INNER ? k : v);
+                return src[(size_t)(o % INNER) * d + kk];
+            };
+            L.finish(a.qkv, lab + ".qkv", h->ldt, 3 * INNER, 1, 1, d, wt, nullptr, nullptr, nullptr);
+        }
+        L.linear(a.out, lab + ".to_out", p + ".to_out.weight", p + ".to_out.bias", d, INNER);
+        L.linear(a.ff1, lab + ".ff1", p + ".ff.net.1.weight", p + ".ff.net.1.bias", DHEAD, d);
+        L.linear(a.ff2, lab + ".ff2", p + ".ff.net.4.weight", p + ".ff.net.4.bias", d, DHEAD);
+        a.n1g = L.vec(p + ".norm1.weight", d); a.n1b = L.vec(p + ".norm1.bias", d);
+        a.n2g = L.vec(p + ".norm2.weight", d); a.n2b = L.vec(p + ".norm2.bias", d);
+        a.fg = L.vec(p + ".ff.net.0.weight", d); a.fb = L.vec(p + ".ff.net.0.bias", d);
+        h->attn.push_back(a);
+    }
+    // ---- decoder: nets.py:119-154
+    if (c.decoder == HMV_DECODER_GCN) {
+        const int dims[4] = {d, 256, 64, 3};
+        for (int i = 0; i < 3; ++i) {
+            const std::string p = "joints_decoder.joints_gcn" + std::to_string(i + 1);
+            const int ci = dims[i], co = dims[i + 1];
+            const HostTensor *w = L.get(p + ".weight", {3, 1, ci, co});
+            const HostTensor *b = L.get(p + ".bias", {1, 1, co});
+            if (w && b) {
+                const float *wd = w->data.data();
+                auto wt = [=](int o, int k) -> float { return wd[((size_t)(o / co) * ci + k) * co + (o % co)]; };
+                L.finish(h->gcn[i], "decoder.gcn" + std::to_string(i + 1), round_up(ci, 32), 3 * co, 1, 1, ci, wt, nullptr,
+                         nullptr, nullptr);
+                h->gcn_bias[i] = L.upload(b->data);
+            }
+        }
+        // Chebyshev polynomials of the fixed hand graph: utils.py:108-120, layers.py:405-445, constants.py:37-41
+        static const int E[20][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {0, 5}, {5, 6}, {6, 7}, {7, 8}, {0, 9}, {9, 10},
+                                     {10, 11}, {11, 12}, {0, 13}, {13, 14}, {14, 15}, {15, 16}, {0, 17}, {17, 18},
+                                     {18, 19}, {19, 20}};
+        float adj[NJ][NJ] = {}, Lp[NJ][NJ];
+        for (auto &e : E) { adj[e[0]][e[1]] = 1.f; adj[e[1]][e[0]] = 1.f; }
+        for (int i = 0; i < NJ; ++i) adj[i][i] += 1.f;
+        for (int i = 0; i < NJ; ++i) {
+            float rs = 0.f;
+            for (int j = 0; j < NJ; ++j) rs += adj[i][j];
+            const float inv = rs != 0.f ? 1.f / rs : 0.f;
+            for (int j = 0; j < NJ; ++j) adj[i][j] *= inv;
+        }
+        float dsq[NJ];
+        for (int i = 0; i < NJ; ++i) {
+            float rs = 0.f;
+            for (int j = 0; j < NJ; ++j) rs += adj[i][j];
+            dsq[i] = 1.f / std::sqrt(rs);
+        }
+        std::vector<float> tk(3 * NJ * NJ);
+        for (int i = 0; i < NJ; ++i)
+            for (int j = 0; j < NJ; ++j) {
+                Lp[i][j] = (i == j ? 1.f : 0.f) - dsq[i] * adj[i][j] * dsq[j];
+                tk[(0 * NJ + i) * NJ + j] = i == j ? 1.f : 0.f;
+                tk[(1 * NJ + i) * NJ + j] = Lp[i][j];
+            }
+        for (int i = 0; i < NJ; ++i)
+            for (int j = 0; j < NJ; ++j) {
+                float s = 0.f;
+                for (int m = 0; m < NJ; ++m) s += Lp[i][m] * Lp[m][j];
+                tk[(2 * NJ + i) * NJ + j] = 2.f * s - (i == j ? 1.f : 0.f);
+            }
+        h->cheb_t = L.upload(tk);
+    } else {
+        L.linear(h->fc1, "decoder.fc1", "joints_decoder.joints_fc1.weight", "joints_decoder.joints_fc1.bias", 64, d);
+        L.linear(h->fc2, "decoder.fc2", "joints_decoder.joints_fc2.weight", "joints_decoder.joints_fc2.bias", 3, 64);
+    }
+    // ---- sinusoidal PE table (plain attribute in the reference, not in the state_dict): layers.py:134-158
+    if (c.pos_enc & HMV_POS_SIN) {
+        const int T = c.num_views * NJ;
+        std::vector<float> pe((size_t)T * d);
+        for (int p = 0; p < T; ++p)
+            for (int cc = 0; cc < d; ++cc) {
+                const int k2 = cc & ~1;
+                const float div = expf((float)k2 * (float)(-std::log(10000.0) / (double)d));
+                const float ang = (float)p * div;
+                pe[(size_t)p * d + cc] = (cc & 1) ? cosf(ang) : sinf(ang);
+            }
+        h->pe = L.upload(pe);
+    } else {
+        h->pe = nullptr;
+    }
+    if (L.rc != HMV_OK) return L.rc;
+    HIPCHK(h, hipDeviceSynchronize());
+    h->finalized = true;
+    h->host.clear();  // host copies are no longer needed
+    return HMV_OK;
+}
+
+}  // extern "C"
+
+// ====================================================================== forward
+namespace {
+
+struct Runner {
+    hmv_engine *h;
+    hipStream_t s;
+    bool dry;
+    int rc = HMV_OK;
+    Arena &A;
+
+    float *alloc(size_t n) { return A.alloc(n); }
+    void release(float *p) { A.release(p); }
+
+    void check(hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == HMV_OK) rc = h->fail(HMV_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    }
+
+    // One conv / GEMM launch.  in: NHWC [N][H][W][L.Cin] ; returns output dims through Ho/Wo.
+    void conv(const Layer &L, const float *in, int N, int H, int W, int stride, int pad_h, int pad_w, float *out, int ldc,
+              const float *res, int ldr, int act, int Ho, int Wo, int rg_out = 0, int rg_in = 0, int scatter = 0, int ooy = 0,
+              int oox = 0) {
+        if (dry || rc != HMV_OK) return;
+        ConvParams p{};
+        p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res; p.out = out;
+        p.N = N; p.H = H; p.W = W; p.Cin = L.Cin;
+        p.Ho = Ho; p.Wo = Wo; p.Cout = L.Cout;
+        p.R = L.R; p.S = L.S; p.stride = stride; p.pad_h = pad_h; p.pad_w = pad_w;
+        p.K = L.K; p.Kpad = L.Kpad;
+        p.M = N * Ho * Wo;
+        p.ldc = ldc; p.ldr = ldr; p.act = act;
+        p.rg_out = rg_out; p.rg_in = rg_in;
+        p.scatter = scatter; p.osy = scatter ? 2 : 1; p.osx = scatter ? 2 : 1; p.ooy = ooy; p.oox = oox;
+        const ConvTile tile = conv_pick_tile(p.M, p.Cout);
+        ProfRec *pr = nullptr;
+        if (h->profiling) {
+            if (h->prof_used == h->prof.size()) {
+                ProfRec r{};
+                check(hipEventCreate(&r.e0), "hipEventCreate");
+                check(hipEventCreate(&r.e1), "hipEventCreate");
+                h->prof.push_back(r);
+            }
+            pr = &h->prof[h->prof_used++];
+            pr->name = conv_tile_name(tile, L.Cin < 32);
+            pr->label = L.label;
+            // algorithmic FLOPs: the real (un-padded) reduction length; the stem's 4th channel is padding
+            const double kreal = (L.Cin == 4) ? (double)L.R * L.S * 3 : (double)L.K;
+            pr->flops = 2.0 * (double)p.M * (double)L.Cout * kreal;
+            check(hipEventRecord(pr->e0, s), "hipEventRecord");
+        }
+        check(launch_conv(p, tile, s), L.label.c_str());
+        if (pr) check(hipEventRecord(pr->e1, s), "hipEventRecord");
+    }
+
+    void gemm(const Layer &L, const float *a, int rows, float *out, int ldc, const float *res, int ldr, int act, int rg_out = 0,
+              int rg_in = 0) {
+        conv(L, a, rows, 1, 1, 1, 0, 0, out, ldc, res, ldr, act, 1, 1, rg_out, rg_in);
+    }
+};
+
+int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const float *intr, float *crop_img, float *joints_cam,
+                float *heatmap, hipStream_t s, bool dry, Arena &A) {
+    Runner R{h, s, dry, HMV_OK, A};
+    const hmv_config &c = h->cfg;
+    const int V = c.num_views, N = B * V, H = c.height, W = c.width;
+    const int d = h->d, ldt = h->ldt;
+#define LAUNCH(expr) do { if (!dry && R.rc == HMV_OK) R.check((expr), #expr); } while (0)
+
+    // ---- stem: conv1 7x7 s2 + BN + ReLU, maxpool 3x3 s2 (resnet.py:218-221)
+    float *in4 = R.alloc((size_t)N * H * W * 4);
+    LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
+    const int H1 = (H + 6 - 7) / 2 + 1, W1 = (W + 6 - 7) / 2 + 1;
+    float *c1 = R.alloc((size_t)N * H1 * W1 * 64);
+    R.conv(h->stem, in4, N, H, W, 2, 3, 3, c1, 64, nullptr, 0, ACT_RELU, H1, W1);
+    R.release(in4);
+    int hh = (H1 + 2 - 3) / 2 + 1, ww = (W1 + 2 - 3) / 2 + 1, C = 64;
+    float *cur = R.alloc((size_t)N * hh * ww * 64);
+    LAUNCH(launch_maxpool3s2(c1, cur, N, H1, W1, 64, hh, ww, s));
+    R.release(c1);
+
+    // ---- residual layers (resnet.py:223-239; Bottleneck 124-144; BasicBlock 90-106)
+    float *level[3] = {nullptr, nullptr, nullptr};
+    int lc[3], lh[3], lw[3];
+    for (int li = 0; li < 3; ++li) {
+        for (size_t bi = 0; bi < h->blocks[li].size(); ++bi) {
+            const Block &b = h->blocks[li][bi];
+            const int ho = (hh + 2 - 3) / b.stride + 1, wo = (ww + 2 - 3) / b.stride + 1;
+            float *y;
+            int outc;
+            if (h->paper) {
+                const int planes = b.c1.Cout;
+                outc = b.c3.Cout;
+                float *t1 = R.alloc((size_t)N * hh * ww * planes);
+                R.conv(b.c1, cur, N, hh, ww, 1, 0, 0, t1, planes, nullptr, 0, ACT_RELU, hh, ww);
+                float *t2 = R.alloc((size_t)N * ho * wo * planes);
+                R.conv(b.c2, t1, N, hh, ww, b.stride, 1, 1, t2, planes, nullptr, 0, ACT_RELU, ho, wo);
+                R.release(t1);
+                const float *res = cur;
+                float *dsb = nullptr;
+                if (b.has_ds) {
+                    dsb = R.alloc((size_t)N * ho * wo * outc);
+                    R.conv(b.ds, cur, N, hh, ww, b.stride, 0, 0, dsb, outc, nullptr, 0, ACT_NONE, ho, wo);
+                    res = dsb;
+                }
+                y = R.alloc((size_t)N * ho * wo * outc);
+                R.conv(b.c3, t2, N, ho, wo, 1, 0, 0, y, outc, res, outc, ACT_RELU, ho, wo);
+                R.release(t2);
+                R.release(dsb);
+            } else {
+                const int planes = b.c1.Cout;
+                outc = planes;
+                float *t1 = R.alloc((size_t)N * ho * wo * planes);
+                R.conv(b.c1, cur, N, hh, ww, b.stride, 1, 1, t1, planes, nullptr, 0, ACT_RELU, ho, wo);
+                const float *res = cur;
+                float *dsb = nullptr;
+                if (b.has_ds) {
+                    dsb = R.alloc((size_t)N * ho * wo * outc);
+                    R.conv(b.ds, cur, N, hh, ww, b.stride, 0, 0, dsb, outc, nullptr, 0, ACT_NONE, ho, wo);
+                    res = dsb;
+                }
+                y = R.alloc((size_t)N * ho * wo * outc);
+                R.conv(b.c2, t1, N, ho, wo, 1, 1, 1, y, outc, res, outc, ACT_RELU, ho, wo);
+                R.release(t1);
+                R.release(dsb);
+            }
+            bool keep = false;
+            for (int q = 0; q < 3; ++q) keep |= (level[q] == cur);
+            if (!keep) R.release(cur);
+            cur = y; C = outc; hh = ho; ww = wo;
+        }
+        // handmvnet.py:165-177: feats = [layer3, layer2, layer1][:n_levels]; keep only what is sampled
+        const bool needed = (li == 2) || (2 - li) < c.n_levels;
+        lc[li] = C; lh[li] = hh; lw[li] = ww;
+        if (needed) level[li] = cur;
+    }
+    float *feat0 = level[2];
+    const int fh = lh[2], fw = lw[2];
+    if (h->capture && !dry && h->cap_feat0) LAUNCH(launch_nhwc_to_nchw(feat0, h->cap_feat0, N, fh, fw, lc[2], s));
+
+    // ---- pose_net (handmvnet.py:70-86, 180) -> channels-last heat map with row stride 32
+    int hmh, hmw;
+    float *hm;
+    if (h->paper) {
+        hmh = fh; hmw = fw;
+        float *ph = R.alloc((size_t)N * fh * fw * 512);
+        R.conv(h->pose0, feat0, N, fh, fw, 1, 0, 0, ph, 512, nullptr, 0, ACT_RELU, fh, fw);
+        hm = R.alloc((size_t)N * hmh * hmw * 32);
+        R.conv(h->pose1, ph, N, fh, fw, 1, 0, 0, hm, 32, nullptr, 0, ACT_NONE, fh, fw);
+        R.release(ph);
+    } else {
+        hmh = 2 * fh; hmw = 2 * fw;
+        float *p0 = R.alloc((size_t)N * hmh * hmw * 128);
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+                R.conv(h->deconv[a * 2 + b], feat0, N, fh, fw, 1, 1 - a, 1 - b, p0, 128, nullptr, 0, ACT_RELU, fh, fw, 0, 0,
+                       /*scatter=*/1, a, b);
+        float *p1 = R.alloc((size_t)N * hmh * hmw * 64);
+        R.conv(h->pose1, p0, N, hmh, hmw, 1, 1, 1, p1, 64, nullptr, 0, ACT_RELU, hmh, hmw);
+        R.release(p0);
+        hm = R.alloc((size_t)N * hmh * hmw * 32);
+        R.conv(h->pose2, p1, N, hmh, hmw, 1, 1, 1, hm, 32, nullptr, 0, ACT_NONE, hmh, hmw);
+        R.release(p1);
+    }
+    // ---- soft-argmax (handmvnet.py:182, 252)
+    float *coords = R.alloc((size_t)N * NJ * 2);
+    LAUNCH(launch_soft_argmax(hm, 32, N, hmh, hmw, coords, crop_img, (float)c.image_size, (float)c.heatmap_size, heatmap, s));
+    R.release(hm);
+    if (h->capture && !dry && h->cap_coords)
+        LAUNCH(hipMemcpyAsync(h->cap_coords, coords, (size_t)N * NJ * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+
+    // ---- sample nets as gather -> conv1x1+BN+ReLU -> bilinear blend (nets.py:46-63; handmvnet.py:185-187)
+    float *tokens = R.alloc((size_t)N * NJ * ldt);
+    int col0 = 0;
+    for (int i = 0; i < c.n_levels; ++i) {
+        const int li = 2 - i, Ci = lc[li], co = Ci / 2;
+        float *g = R.alloc((size_t)N * NJ * 4 * Ci);
+        LAUNCH(launch_sample_gather(level[li], N, lh[li], lw[li], Ci, coords, g, s));
+        float *s4 = R.alloc((size_t)N * NJ * 4 * co);
+        R.gemm(h->sample[i], g, N * NJ * 4, s4, co, nullptr, 0, ACT_RELU);
+        R.release(g);
+        LAUNCH(launch_sample_blend(s4, co, co, N, lh[li], lw[li], coords, tokens, ldt, col0, s));
+        R.release(s4);
+        col0 += co;
+    }
+    for (int li = 0; li < 3; ++li) R.release(level[li]);
+    // pos2d / FoV / zero pad / PE (handmvnet.py:189-225; fusion.py:27-28)
+    LAUNCH(launch_tokens_finalize(tokens, ldt, d, h->fdim, N, V, coords, bbox, intr, c.pos_enc, h->pe,
+                                  (h->capture && h->cap_tokens) ? h->cap_tokens : nullptr, s));
+    R.release(coords);
+
+    // ---- CrossAttentionFusion (fusion.py:7-30; layers.py:202-237)
+    float *X = tokens;
+    int Tcur = V * NJ;
+    const int half = (c.fusion_layers - 1) / 2;
+    for (int l = 0; l < c.fusion_layers; ++l) {
+        const AttnLayer &a = h->attn[l];
+        const bool cross = (l == half);
+        const int Tq = cross ? NJ : Tcur, koff = cross ? NJ : 0, Tk = cross ? Tcur - NJ : Tcur;
+        const int rows = B * Tcur, qrows = B * Tq;
+        float *qkv = R.alloc((size_t)rows * 3 * INNER);
+        R.gemm(a.qkv, X, rows, qkv, 3 * INNER, nullptr, 0, ACT_NONE);
+        float *att = R.alloc((size_t)qrows * INNER);
+        if (Tk > 0) LAUNCH(launch_attention(qkv, B, Tcur, Tq, koff, Tk, att, s));
+        else LAUNCH(hipMemsetAsync(att, 0, (size_t)qrows * INNER * sizeof(float), s));
+        R.release(qkv);
+        float *o = R.alloc((size_t)qrows * ldt);
+        R.gemm(a.out, att, qrows, o, ldt, X, ldt, ACT_NONE, cross ? Tq : 0, cross ? Tcur : 0);  // + _q
+        R.release(att);
+        float *n1 = R.alloc((size_t)qrows * ldt), *f0 = R.alloc((size_t)qrows * ldt);
+        LAUNCH(launch_layernorm(o, ldt, qrows, d, a.n1g, a.n1b, n1, ldt, a.fg, a.fb, f0, s));
+        R.release(o);
+        float *f1 = R.alloc((size_t)qrows * DHEAD);
+        R.gemm(a.ff1, f0, qrows, f1, DHEAD, nullptr, 0, ACT_GELU);
+        R.release(f0);
+        float *f2 = R.alloc((size_t)qrows * ldt);
+        R.gemm(a.ff2, f1, qrows, f2, ldt, n1, ldt, ACT_NONE);
+        R.release(f1);
+        float *Xn = R.alloc((size_t)qrows * ldt);
+        LAUNCH(launch_layernorm(f2, ldt, qrows, d, a.n2g, a.n2b, Xn, ldt, nullptr, nullptr, nullptr, s));
+        R.release(f2);
+        R.release(n1);
+        R.release(X);
+        X = Xn;
+        Tcur = Tq;
+    }
+    if (h->capture && !dry && h->cap_fused) LAUNCH(launch_copy_rows(X, ldt, h->cap_fused, d, B * Tcur, d, s));
+
+    // ---- decoder (nets.py:133-139 / 150-154)
+    const int jr = B * NJ;
+    if (c.decoder == HMV_DECODER_GCN) {
+        const int dims[4] = {d, 256, 64, 3};
+        float *xin = X;
+        for (int i = 0; i < 3; ++i) {
+            const int co = dims[i + 1];
+            float *y = R.alloc((size_t)jr * 3 * co);
+            R.gemm(h->gcn[i], xin, jr, y, 3 * co, nullptr, 0, ACT_NONE);
+            R.release(xin);
+            float *out = i == 2 ? joints_cam : R.alloc((size_t)jr * co);
+            LAUNCH(launch_cheb_mix(y, 3 * co, B, co, h->cheb_t, h->gcn_bias[i], i < 2, out, i == 2 ? 3 : co, s));
+            R.release(y);
+            xin = i == 2 ? nullptr : out;
+        }
+    } else {
+        float *g1 = R.alloc((size_t)jr * 64);
+        R.gemm(h->fc1, X, jr, g1, 64, nullptr, 0, ACT_LEAKY);
+        R.release(X);
+        R.gemm(h->fc2, g1, jr, joints_cam, 3, nullptr, 0, ACT_NONE);
+        R.release(g1);
+    }
+#undef LAUNCH
+    return R.rc;
+}
+
+int ensure_capture(hmv_engine *h, int B) {
+    if (!h->capture || h->cap_batch >= B) return HMV_OK;
+    const hmv_config &c = h->cfg;
+    const int N = B * c.num_views;
+    const int fdiv = h->paper ? 8 : 16;
+    for (float **p : {&h->cap_feat0, &h->cap_coords, &h->cap_tokens, &h->cap_fused}) {
+        if (*p) hipFree(*p);
+        *p = nullptr;
+    }
+    h->cap_feat0_n = (size_t)N * c.channels[0] * (c.height / fdiv) * (c.width / fdiv);
+    h->cap_coords_n = (size_t)N * NJ * 2;
+    h->cap_tokens_n = (size_t)N * NJ * h->d;
+    h->cap_fused_n = (size_t)B * NJ * h->d;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->cap_feat0), h->cap_feat0_n * sizeof(float)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->cap_coords), h->cap_coords_n * sizeof(float)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->cap_tokens), h->cap_tokens_n * sizeof(float)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->cap_fused), h->cap_fused_n * sizeof(float)));
+    h->cap_batch = B;
+    return HMV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hmv_workspace_bytes(hmv_handle h, int32_t batch) {
+    if (!h || batch <= 0) return 0;
+    Arena dry;
+    dry.reset(reinterpret_cast<char *>(uintptr_t(1) << 40));  // fake non-null base: offsets only
+    const bool saved = h->profiling;
+    h->profiling = false;
+    run_forward(h, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, /*dry=*/true, dry);
+    h->profiling = saved;
+    return dry.high;
+}
+
+int hmv_reserve(hmv_handle h, int32_t batch) {
+    if (!h || batch <= 0) return h ? h->fail(HMV_ERR_ARG, "batch must be positive") : HMV_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (batch > h->reserved_batch) {
+        const size_t need = hmv_workspace_bytes(h, batch);
+        if (h->arena) {
+            HIPCHK(h, hipDeviceSynchronize());
+            HIPCHK(h, hipFree(h->arena));
+            h->arena = nullptr;
+        }
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->arena), need));
+        h->arena_bytes = need;
+        h->reserved_batch = batch;
+    }
+    return ensure_capture(h, batch);
+}
+
+int hmv_forward(hmv_handle h, int32_t batch, const float *x, const float *bbox, const float *intrinsic, float *joints_crop_img,
+                float *joints_cam, float *heatmap, void *stream) {
+    if (!h) return HMV_ERR_ARG;
+    if (!h->finalized) return h->fail(HMV_ERR_STATE, "hmv_finalize_weights has not succeeded on this handle");
+    if (batch <= 0 || !x || !joints_crop_img || !joints_cam) return h->fail(HMV_ERR_ARG, "null or empty input/output");
+    if ((h->cfg.pos_enc & HMV_POS_CROP) && (!bbox || !intrinsic))
+        return h->fail(HMV_ERR_ARG, "pos_enc contains 'crop': bbox and cam_params['intrinsic'] are required");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (batch > h->reserved_batch || (h->capture && h->cap_batch < batch)) {
+        const int rc = hmv_reserve(h, batch);
+        if (rc != HMV_OK) return rc;
+    }
+    h->plan.reset(h->arena);
+    const int rc = run_forward(h, batch, x, bbox, intrinsic, joints_crop_img, joints_cam, heatmap, static_cast<hipStream_t>(stream),
+                               false, h->plan);
+    if (rc == HMV_OK && h->plan.high > h->arena_bytes) return h->fail(HMV_ERR_STATE, "workspace plan exceeded its reservation");
+    return rc;
+}
+
+void hmv_destroy(hmv_handle h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    hipDeviceSynchronize();
+    for (void *p : h->dev_allocs) hipFree(p);
+    if (h->arena) hipFree(h->arena);
+    for (float *p : {h->cap_feat0, h->cap_coords, h->cap_tokens, h->cap_fused})
+        if (p) hipFree(p);
+    for (auto &r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    delete h;
+}
+
+int hmv_set_capture(hmv_handle h, int32_t enable) {
+    if (!h) return HMV_ERR_ARG;
+    h->capture = enable != 0;
+    return HMV_OK;
+}
+
+int hmv_read_stage(hmv_handle h, const char *stage, float *dst, size_t capacity, void *stream) {
+    if (!h || !stage || !dst) return HMV_ERR_ARG;
+    const float *src = nullptr;
+    size_t n = 0;
+    const std::string st(stage);
+    if (st == "feat0") { src = h->cap_feat0; n = h->cap_feat0_n; }
+    else if (st == "coords_hm") { src = h->cap_coords; n = h->cap_coords_n; }
+    else if (st == "tokens") { src = h->cap_tokens; n = h->cap_tokens_n; }
+    else if (st == "fused") { src = h->cap_fused; n = h->cap_fused_n; }
+    else return h->fail(HMV_ERR_ARG, "unknown stage %s", stage);
+    if (!src) return h->fail(HMV_ERR_STATE, "stage capture was not enabled before the forward");
+    if (capacity < n) n = capacity;
+    HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return HMV_OK;
+}
+
+int hmv_set_profiling(hmv_handle h, int32_t enable) {
+    if (!h) return HMV_ERR_ARG;
+    h->profiling = enable != 0;
+    h->prof_used = 0;  // (re)enabling starts a fresh record list; records accumulate across forwards
+    return HMV_OK;
+}
+
+int hmv_profile_count(hmv_handle h) { return h ? (int)h->prof_used : 0; }
+
+int hmv_profile_get(hmv_handle h, int32_t index, const char **name, const char **label, float *ms, double *flops) {
+    if (!h || index < 0 || (size_t)index >= h->prof_used) return HMV_ERR_ARG;
+    ProfRec &r = h->prof[index];
+    float t = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&t, r.e0, r.e1));
+    if (name) *name = r.name;
+    if (label) *label = r.label.c_str();
+    if (ms) *ms = t;
+    if (flops) *flops = r.flops;
+    return HMV_OK;
+}
+
+int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *w_oihw,
+                  const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad, const float *residual,
+                  int32_t relu, float *out, void *stream) {
+    if (!in || !w_oihw || !out || Cin % 4 != 0 || (Cin >= 32 && Cin % 32 != 0) || (Cin < 32 && Cin != 4)) {
+        g_create_err = "hmv_op_conv2d: Cin must be 4 or a multiple of 32";
+        return HMV_ERR_ARG;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
+    const int K = R * S * Cin, Kpad = round_up(K, 32), Cp = round_up(Cout, 128);
+    std::vector<float> w((size_t)Cp * Kpad, 0.f), b((size_t)Cp, 0.f);
+    for (int o = 0; o < Cout; ++o) {
+        for (int k = 0; k < K; ++k) {
+            const int c = k % Cin, tap = k / Cin;
+            w[(size_t)o * Kpad + k] = w_oihw[(((size_t)o * Cin + c) * R + tap / S) * S + tap % S];
+        }
+        if (bias_host) b[o] = bias_host[o];
+    }
+    float *dw = nullptr, *db = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dw), w.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&db), b.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(dw, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        ConvParams p{};
+        p.in = in; p.wgt = dw; p.bias = db; p.res = residual; p.out = out;
+        p.N = N; p.H = H; p.W = W; p.Cin = Cin;
+        p.Ho = (H + 2 * pad - R) / stride + 1; p.Wo = (W + 2 * pad - S) / stride + 1; p.Cout = Cout;
+        p.R = R; p.S = S; p.stride = stride; p.pad_h = pad; p.pad_w = pad;
+        p.K = K; p.Kpad = Kpad; p.M = N * p.Ho * p.Wo; p.ldc = Cout; p.ldr = Cout;
+        p.act = relu ? ACT_RELU : ACT_NONE; p.osy = p.osx = 1;
+        e = launch_conv(p, conv_pick_tile(p.M, Cout), static_cast<hipStream_t>(stream));
+        if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    }
+    if (dw) hipFree(dw);
+    if (db) hipFree(db);
+    if (e != hipSuccess) { g_create_err = std::string("hmv_op_conv2d: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
+    return HMV_OK;
+}
+
+}  // extern "C"

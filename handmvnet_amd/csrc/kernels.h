@@ -1,0 +1,69 @@
+// Internal launcher interface between engine.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hmv {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_LEAKY = 3 };
+
+// Implicit-GEMM convolution / plain GEMM on fp32 MFMA.
+//   out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] + res[m'][n] )
+// A[m][k] is gathered on the fly from an NHWC tensor: m = (img, ho, wo), k = (r, s, c).
+// A plain row-major GEMM is the special case H = W = R = S = 1, N = M, Cin = K.
+struct ConvParams {
+    const float *in;    // NHWC [N][H][W][Cin]
+    const float *wgt;   // [Cout_pad][Kpad], K ordered (r, s, c), zero padded
+    const float *bias;  // [Cout_pad] (folded BN shift + conv bias), never null
+    const float *res;   // residual, row-major [M'][ldr] or null
+    float *out;         // [M''][ldc]
+    int N, H, W, Cin;
+    int Ho, Wo, Cout;
+    int R, S, stride, pad_h, pad_w;
+    int K, Kpad;        // K = R*S*Cin; Kpad = K rounded up to 32
+    int M;              // N*Ho*Wo
+    int ldc, ldr;
+    int act;
+    int rg_out, rg_in;  // residual row remap: row' = (m / rg_out) * rg_in + m % rg_out (rg_out = 0: identity)
+    int scatter;        // output pixel (ho*osy + ooy, wo*osx + oox) in an (Ho*osy) x (Wo*osx) image
+    int osy, osx, ooy, oox;
+    int mtiles, ntiles;
+};
+
+enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_COUNT = 3 };
+int conv_tile_bn(ConvTile t);                       // N-tile width of a tile config
+const char *conv_tile_name(ConvTile t, bool smallc);
+ConvTile conv_pick_tile(int M, int Cout);
+// fills mtiles/ntiles and launches
+hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s);
+
+// ---- small kernels
+hipError_t launch_nchw_to_nhwc4(const float *x, float *out, int N, int H, int W, hipStream_t s);
+hipError_t launch_maxpool3s2(const float *in, float *out, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
+// hm: [N*h*w][ld] (channels-last heat map, 21 valid columns) -> coords [N][21][2] (heat-map px),
+// joints_crop_img = coords * image_size / heatmap_size, optional NCHW heat map copy.
+hipError_t launch_soft_argmax(const float *hm, int ld, int N, int h, int w, float *coords, float *crop_img,
+                              float image_size, float heatmap_size, float *hm_nchw, hipStream_t s);
+// gathers the 4 bilinear neighbours of every joint: out [(n*21+j)*4 + t][C] (zeros when out of range)
+hipError_t launch_sample_gather(const float *feat, int N, int H, int W, int C, const float *coords, float *out,
+                                hipStream_t s);
+// tokens[(n*21+j)][col0 + c] = sum_t w_t * s[(n*21+j)*4+t][c]
+hipError_t launch_sample_blend(const float *s4, int lds4, int C, int N, int H, int W, const float *coords,
+                               float *tokens, int ldt, int col0, hipStream_t s);
+// pos2d / FoV columns, zero padding columns; optional raw copy (before PE) and PE add
+hipError_t launch_tokens_finalize(float *tokens, int ldt, int d, int fdim, int N, int V, const float *coords,
+                                  const float *bbox, const float *intr, int pos_mask, const float *pe,
+                                  float *raw_copy, hipStream_t s);
+// y = LN(x) ; optional second LN applied to y -> y2.  Pads [d, ld) are written as zeros.
+hipError_t launch_layernorm(const float *x, int ldx, int rows, int d, const float *g1, const float *b1, float *y,
+                            int ldy, const float *g2, const float *b2, float *y2, hipStream_t s);
+// softmax(q k^T / sqrt(128)) v per (sample, head); qkv rows are [q | k | v] of width 3*1024.
+hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s);
+// Chebyshev mix: out[b][i][o] = act(sum_k sum_j Tk[k][i][j] * y[b*21+j][k*co + o] + bias[o])
+hipError_t launch_cheb_mix(const float *y, int ldy, int B, int co, const float *tk, const float *bias, int leaky,
+                           float *out, int ldo, hipStream_t s);
+// NHWC -> NCHW copy (stage capture)
+hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t s);
+hipError_t launch_copy_rows(const float *in, int ldi, float *out, int ldo, int rows, int cols, hipStream_t s);
+
+}  // namespace hmv

@@ -1,0 +1,450 @@
+// misc_kernels.hip -- the memory-bound / small kernels around the conv-GEMM family.
+// All are HBM- or latency-bound; they are written for coalesced 16-byte accesses and
+// 64-lane wave reductions (gfx950 wavefront = 64).
+#include "kernels.h"
+
+namespace hmv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------ frames: NCHW fp32 -> NHWC4
+// x.view(-1, c, h, w) of handmvnet.py:163 ; the 4th channel is a zero so that one conv tap
+// is one aligned 16-byte vector for the stem's implicit GEMM.
+__global__ void nchw_to_nhwc4_kernel(const float *__restrict__ x, f32x4 *__restrict__ out, int HW, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const size_t n = i / HW, pix = i - n * HW;
+        const float *src = x + n * 3 * (size_t)HW + pix;
+        out[i] = f32x4{src[0], src[HW], src[2 * (size_t)HW], 0.f};
+    }
+}
+hipError_t launch_nchw_to_nhwc4(const float *x, float *out, int N, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)N * H * W;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<f32x4 *>(out), H * W, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ MaxPool2d(3, stride 2, pad 1), NHWC
+// resnet.py:165,221
+__global__ void maxpool3s2_kernel(const f32x4 *__restrict__ in, f32x4 *__restrict__ out, int H, int W, int C4, int Ho,
+                                  int Wo, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % C4);
+        size_t t = i / C4;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const size_t n = t / Ho;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = ho * 2 - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int wi = wo * 2 - 1 + q;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = in[((n * H + hi) * W + wi) * C4 + c];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        out[i] = m;
+    }
+}
+hipError_t launch_maxpool3s2(const float *in, float *out, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(in),
+                       reinterpret_cast<f32x4 *>(out), H, W, C / 4, Ho, Wo, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ soft_argmax_2d (temperature 1000)
+// models/utils.py:35-62.  One wave per (image, joint); logits stay fp32 end to end.
+__global__ void soft_argmax_kernel(const float *__restrict__ hm, int ld, int h, int w, int total, float *coords,
+                                   float *crop_img, float image_size, float heatmap_size, float *hm_nchw) {
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wid >= total) return;
+    const int n = wid / 21, j = wid - n * 21, hw = h * w;
+    const float *src = hm + (size_t)n * hw * ld + j;
+    float mx = -INFINITY;
+    for (int p = lane; p < hw; p += 64) {
+        const float raw = src[(size_t)p * ld];
+        if (hm_nchw) hm_nchw[((size_t)n * 21 + j) * hw + p] = raw;
+        mx = fmaxf(mx, raw * 1000.0f);
+    }
+    mx = wave_max(mx);
+    float se = 0.f, sx = 0.f, sy = 0.f;
+    for (int p = lane; p < hw; p += 64) {
+        const float e = expf(src[(size_t)p * ld] * 1000.0f - mx);
+        const int y = p / w, x = p - y * w;
+        se += e;
+        sx += e * (float)x;
+        sy += e * (float)y;
+    }
+    se = wave_sum(se);
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    if (lane == 0) {
+        const float cx = sx / se, cy = sy / se;
+        coords[2 * wid] = cx;
+        coords[2 * wid + 1] = cy;
+        crop_img[2 * wid] = cx * image_size / heatmap_size;  // handmvnet.py:252
+        crop_img[2 * wid + 1] = cy * image_size / heatmap_size;
+    }
+}
+hipError_t launch_soft_argmax(const float *hm, int ld, int N, int h, int w, float *coords, float *crop_img,
+                              float image_size, float heatmap_size, float *hm_nchw, hipStream_t s) {
+    const int total = N * 21;
+    hipLaunchKernelGGL(soft_argmax_kernel, dim3((total + 3) / 4), dim3(256), 0, s, hm, ld, h, w, total, coords, crop_img,
+                       image_size, heatmap_size, hm_nchw);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ SampleNet: gather-then-conv
+// nets.py:46-63.  conv1x1+BN+ReLU is pointwise, so conv(map) sampled at 4 taps == conv applied to
+// the 4 gathered input pixels; the bilinear blend (with zero padding) follows.  The unnormalise
+// arithmetic replays F.grid_sample(align_corners=True) in fp32.
+struct Taps {
+    int x0, y0;
+    float w[4];   // nw, ne, sw, se
+    bool v[4];
+};
+__device__ __forceinline__ Taps bilinear_taps(float jx, float jy, int H, int W) {
+    const float gx = jx / (float)(W - 1) * 2.f - 1.f, gy = jy / (float)(H - 1) * 2.f - 1.f;
+    const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1), iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    Taps t;
+    // clamp before the int conversion so that absurd coordinates cannot overflow; they are invalid anyway
+    t.x0 = (int)fminf(fmaxf(fx0, -4.f), (float)W + 4.f);
+    t.y0 = (int)fminf(fmaxf(fy0, -4.f), (float)H + 4.f);
+    const float x1 = fx0 + 1.f, y1 = fy0 + 1.f;
+    t.w[0] = (x1 - ix) * (y1 - iy);
+    t.w[1] = (ix - fx0) * (y1 - iy);
+    t.w[2] = (x1 - ix) * (iy - fy0);
+    t.w[3] = (ix - fx0) * (iy - fy0);
+    const bool vx0 = t.x0 >= 0 && t.x0 < W, vx1 = t.x0 + 1 >= 0 && t.x0 + 1 < W;
+    const bool vy0 = t.y0 >= 0 && t.y0 < H, vy1 = t.y0 + 1 >= 0 && t.y0 + 1 < H;
+    const bool fin = (fx0 == fx0) && (fy0 == fy0);  // NaN coordinates sample nothing
+    t.v[0] = fin && vy0 && vx0;
+    t.v[1] = fin && vy0 && vx1;
+    t.v[2] = fin && vy1 && vx0;
+    t.v[3] = fin && vy1 && vx1;
+    return t;
+}
+
+__global__ void sample_gather_kernel(const f32x4 *__restrict__ feat, int H, int W, int C4, const float *__restrict__ coords,
+                                     f32x4 *__restrict__ out) {
+    const int row = blockIdx.x;  // n*21 + j
+    const int n = row / 21;
+    const Taps t = bilinear_taps(coords[2 * row], coords[2 * row + 1], H, W);
+    for (int i = threadIdx.x; i < 4 * C4; i += blockDim.x) {
+        const int tap = i / C4, c = i - tap * C4;
+        const int x = t.x0 + (tap & 1), y = t.y0 + (tap >> 1);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t.v[tap]) v = feat[(((size_t)n * H + y) * W + x) * C4 + c];
+        out[((size_t)row * 4 + tap) * C4 + c] = v;
+    }
+}
+hipError_t launch_sample_gather(const float *feat, int N, int H, int W, int C, const float *coords, float *out,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(sample_gather_kernel, dim3(N * 21), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(feat), H, W,
+                       C / 4, coords, reinterpret_cast<f32x4 *>(out));
+    return hipGetLastError();
+}
+
+__global__ void sample_blend_kernel(const float *__restrict__ s4, int lds4, int C, int H, int W,
+                                    const float *__restrict__ coords, float *__restrict__ tokens, int ldt, int col0) {
+    const int row = blockIdx.x;
+    const Taps t = bilinear_taps(coords[2 * row], coords[2 * row + 1], H, W);
+    const float *b = s4 + (size_t)row * 4 * lds4;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float v = 0.f;  // same accumulation order as grid_sample: nw, ne, sw, se
+        if (t.v[0]) v += b[c] * t.w[0];
+        if (t.v[1]) v += b[lds4 + c] * t.w[1];
+        if (t.v[2]) v += b[2 * lds4 + c] * t.w[2];
+        if (t.v[3]) v += b[3 * lds4 + c] * t.w[3];
+        tokens[(size_t)row * ldt + col0 + c] = v;
+    }
+}
+hipError_t launch_sample_blend(const float *s4, int lds4, int C, int N, int H, int W, const float *coords, float *tokens,
+                               int ldt, int col0, hipStream_t s) {
+    hipLaunchKernelGGL(sample_blend_kernel, dim3(N * 21), dim3(128), 0, s, s4, lds4, C, H, W, coords, tokens, ldt, col0);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ token tail
+// pos2d (handmvnet.py:189-191), crop FoV (handmvnet.py:205-222, utils.py:134-171), zero pad,
+// optional capture of the raw tokens, then + sinusoidal PE (layers.py:152-158; table built on host).
+__global__ void tokens_finalize_kernel(float *tokens, int ldt, int d, int fdim, int V, const float *coords,
+                                       const float *bbox, const float *intr, int pos_mask, const float *pe,
+                                       float *raw_copy) {
+    const int row = blockIdx.x;           // n*21 + j, n = b*V + v
+    const int n = row / 21, j = row - n * 21;
+    float *t = tokens + (size_t)row * ldt;
+    int col = fdim;
+    if (threadIdx.x == 0) {
+        if (pos_mask & 1) { t[col] = coords[2 * row]; t[col + 1] = coords[2 * row + 1]; }
+    }
+    if (pos_mask & 1) col += 2;
+    if ((pos_mask & 2) && threadIdx.x < 10) {
+        const float *bb = bbox + 4 * n, *in = intr + 4 * n;
+        const int pt = threadIdx.x >> 1, isy = threadIdx.x & 1;
+        float px, py;
+        if (pt == 0) { px = bb[0]; py = bb[1]; }
+        else if (pt == 1) { px = bb[0]; py = bb[3]; }
+        else if (pt == 2) { px = bb[2]; py = bb[1]; }
+        else if (pt == 3) { px = bb[2]; py = bb[3]; }
+        else { px = (bb[0] + bb[2]) / 2.f; py = (bb[1] + bb[3]) / 2.f; }
+        t[col + threadIdx.x] = isy ? atanf((py - in[3]) / in[1]) : atanf((px - in[2]) / in[0]);
+    }
+    for (int c = d + threadIdx.x; c < ldt; c += blockDim.x) t[c] = 0.f;
+    __syncthreads();
+    const int pos = (n % V) * 21 + j;  // token index inside its sample, view-major
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        const float v = t[c];
+        if (raw_copy) raw_copy[(size_t)row * d + c] = v;
+        if (pe) t[c] = v + pe[(size_t)pos * d + c];
+    }
+}
+hipError_t launch_tokens_finalize(float *tokens, int ldt, int d, int fdim, int N, int V, const float *coords,
+                                  const float *bbox, const float *intr, int pos_mask, const float *pe, float *raw_copy,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL(tokens_finalize_kernel, dim3(N * 21), dim3(128), 0, s, tokens, ldt, d, fdim, V, coords, bbox, intr,
+                       pos_mask, pe, raw_copy);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ LayerNorm (+ optional chained LayerNorm)
+// layers.py:194-195 (norm1/norm2), layers.py:165 (FeedForward's leading LayerNorm); eps 1e-5.
+// One wave per row, two-pass (mean, then centred variance) in registers.
+constexpr int LN_MAX_PER_LANE = 16;  // d <= 1024
+__global__ void layernorm_kernel(const float *__restrict__ x, int ldx, int rows, int d, const float *__restrict__ g1,
+                                 const float *__restrict__ b1, float *__restrict__ y, int ldy,
+                                 const float *__restrict__ g2, const float *__restrict__ b2, float *__restrict__ y2) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * ldx;
+    float v[LN_MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < d ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float inv_d = 1.f / (float)d;
+    float mean = wave_sum(s) * inv_d, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        const float t = c < d ? v[i] - mean : 0.f;
+        q += t * t;
+    }
+    float rstd = 1.f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d) {
+            v[i] = (v[i] - mean) * rstd * g1[c] + b1[c];
+            y[(size_t)row * ldy + c] = v[i];
+            s += v[i];
+        } else if (c < ldy) {
+            y[(size_t)row * ldy + c] = 0.f;
+        }
+    }
+    if (!y2) return;
+    mean = wave_sum(s) * inv_d;
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        const float t = c < d ? v[i] - mean : 0.f;
+        q += t * t;
+    }
+    rstd = 1.f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d) y2[(size_t)row * ldy + c] = (v[i] - mean) * rstd * g2[c] + b2[c];
+        else if (c < ldy) y2[(size_t)row * ldy + c] = 0.f;
+    }
+}
+hipError_t launch_layernorm(const float *x, int ldx, int rows, int d, const float *g1, const float *b1, float *y, int ldy,
+                            const float *g2, const float *b2, float *y2, hipStream_t s) {
+    if (d > 64 * LN_MAX_PER_LANE || ldy > 64 * LN_MAX_PER_LANE) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, d, g1, b1, y, ldy, g2, b2, y2);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ attention, one workgroup per (sample, head)
+// layers.py:216-221: dots = q k^T * 128^-0.5 ; softmax ; attn v.  T <= 256 keys: the whole K of a head
+// sits in LDS ([Tk][129] floats, conflict-free for "lane = key" reads); each wave owns query rows
+// i = wave, wave+4, ...: lane = key for the scores, lane = channel pair for P.V (V streamed from L2).
+constexpr int ATT_KPL = 4;  // keys per lane -> Tk <= 256
+__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ qkv, int T, int Tq, int koff, int Tk,
+                                                        float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *sK = sm;                 // [Tk][129]
+    float *sQ = sm + Tk * 129;      // [4 waves][128]
+    float *sP = sQ + 4 * 128;       // [4 waves][Tk]
+    const int b = blockIdx.x >> 3, h = blockIdx.x & 7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t ld = 3 * 1024;
+    const float *base = qkv + (size_t)b * T * ld;
+    for (int i = tid; i < Tk * 32; i += 256) {
+        const int j = i >> 5, c4 = i & 31;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (size_t)(koff + j) * ld + 1024 + h * 128 + 4 * c4);
+        float *dst = sK + j * 129 + 4 * c4;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    __syncthreads();
+    const float scale = 0.08838834764831845f;  // 128 ** -0.5
+    float *q = sQ + wave * 128, *pr = sP + wave * Tk;
+    for (int i = wave; i < Tq; i += 4) {
+        const float *qrow = base + (size_t)i * ld + h * 128;
+        q[lane] = qrow[lane];
+        q[lane + 64] = qrow[lane + 64];
+        __builtin_amdgcn_wave_barrier();
+        float sc[ATT_KPL], mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < ATT_KPL; ++u) {
+            const int j = lane + 64 * u;
+            float a = 0.f;
+            if (j < Tk) {
+                const float *kr = sK + j * 129;
+#pragma unroll 8
+                for (int c = 0; c < 128; ++c) a += q[c] * kr[c];
+                a *= scale;
+                mx = fmaxf(mx, a);
+            }
+            sc[u] = a;
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < ATT_KPL; ++u) {
+            const int j = lane + 64 * u;
+            if (j < Tk) {
+                sc[u] = expf(sc[u] - mx);
+                sum += sc[u];
+            }
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int u = 0; u < ATT_KPL; ++u) {
+            const int j = lane + 64 * u;
+            if (j < Tk) pr[j] = sc[u] * inv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float o0 = 0.f, o1 = 0.f;
+        const float *vbase = base + (size_t)koff * ld + 2048 + h * 128 + 2 * lane;
+        for (int j = 0; j < Tk; ++j) {
+            const float2 vv = *reinterpret_cast<const float2 *>(vbase + (size_t)j * ld);
+            const float pj = pr[j];
+            o0 += pj * vv.x;
+            o1 += pj * vv.y;
+        }
+        float *orow = out + ((size_t)b * Tq + i) * 1024 + h * 128 + 2 * lane;
+        *reinterpret_cast<float2 *>(orow) = make_float2(o0, o1);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s) {
+    if (Tk > 64 * ATT_KPL) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)Tk * 129 + 4 * 128 + 4 * (size_t)Tk) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(attention_kernel, dim3(B * 8), dim3(256), lds, s, qkv, T, Tq, koff, Tk, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ ChebConv mix
+// layers.py:387-403: sum_k T_k (X W_k) + b, the X W_k products come from one GEMM with N = 3*co.
+__global__ void cheb_mix_kernel(const float *__restrict__ y, int ldy, int co, const float *__restrict__ tk,
+                                const float *__restrict__ bias, int leaky, float *__restrict__ out, int ldo) {
+    __shared__ float sT[3 * 21 * 21];
+    for (int i = threadIdx.x; i < 3 * 21 * 21; i += blockDim.x) sT[i] = tk[i];
+    __syncthreads();
+    const int b = blockIdx.x;
+    const float *yb = y + (size_t)b * 21 * ldy;
+    for (int idx = threadIdx.x; idx < 21 * co; idx += blockDim.x) {
+        const int i = idx / co, o = idx - i * co;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float part = 0.f;
+            for (int j = 0; j < 21; ++j) part += sT[(k * 21 + i) * 21 + j] * yb[(size_t)j * ldy + k * co + o];
+            acc += part;
+        }
+        float v = acc + bias[o];
+        if (leaky) v = v > 0.f ? v : 0.01f * v;
+        out[((size_t)b * 21 + i) * ldo + o] = v;
+    }
+}
+hipError_t launch_cheb_mix(const float *y, int ldy, int B, int co, const float *tk, const float *bias, int leaky,
+                           float *out, int ldo, hipStream_t s) {
+    hipLaunchKernelGGL(cheb_mix_kernel, dim3(B), dim3(256), 0, s, y, ldy, co, tk, bias, leaky, out, ldo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ capture helpers
+__global__ void nhwc_to_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, int HW, int C, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {  // i indexes the NCHW output
+        const int p = (int)(i % HW);
+        const size_t t = i / HW;
+        const int c = (int)(t % C);
+        const size_t n = t / C;
+        out[i] = in[(n * HW + p) * C + c];
+    }
+}
+hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t s) {
+    const size_t total = (size_t)N * H * W * C;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid), dim3(256), 0, s, in, out, H * W, C, total);
+    return hipGetLastError();
+}
+
+__global__ void copy_rows_kernel(const float *__restrict__ in, int ldi, float *__restrict__ out, int ldo, int cols,
+                                 size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const size_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        out[r * ldo + c] = in[r * ldi + c];
+    }
+}
+hipError_t launch_copy_rows(const float *in, int ldi, float *out, int ldo, int rows, int cols, hipStream_t s) {
+    const size_t total = (size_t)rows * cols;
+    if (!total) return hipSuccess;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(256), 0, s, in, ldi, out, ldo, cols, total);
+    return hipGetLastError();
+}
+
+}  // namespace hmv

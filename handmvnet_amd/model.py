@@ -1,0 +1,214 @@
+"""Drop-in mirror of the reference's ``HandMvNet`` for the inference forward pass.
+
+Same constructor, same ``forward(x, bbox, cam_params) -> dict`` and the same ``state_dict``
+key layout as /root/reference/src/models/handmvnet.py:27-266, routed to the MI355X engine
+(libhandmv.so) through the C ABI of include/handmv.h.  Training hooks, losses, metrics and
+the MANO mesh step are outside the accelerated hot path.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .spec import BACKBONE_IDS, HotPathConfig, config_from_params, executed_keys, remap_legacy_keys, state_dict_layout
+from .synth import synth_state_dict
+
+
+def _np(v) -> np.ndarray:
+    if isinstance(v, torch.Tensor):
+        return v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+class HandMvNet(torch.nn.Module):
+    """HandMvNet(train_params, model_params, data_params) -- handmvnet.py:28."""
+
+    def __init__(self, train_params: dict, model_params: dict, data_params: dict, init_seed: int = 0):
+        super().__init__()
+        self.train_params, self.model_params, self.data_params = train_params, model_params, data_params
+        self.cfg: HotPathConfig = config_from_params(train_params, model_params, data_params)
+        if self.cfg.backbone_type != "50_paper" and self.cfg.early_return != 3:
+            raise NotImplementedError("ResNet-18/34 are supported with backbone_early_return=3 (every release config)")
+        self.debug = train_params["debug"]
+        self.num_views = self.cfg.num_views
+        self.batch_size = data_params["batch_size"]
+        self.feat_dim = self.cfg.feat_dim
+        self.pos_enc_list = list(self.cfg.pos_enc)
+        self.fusion_layers = self.cfg.fusion_layers
+        self.example_input_array = {  # handmvnet.py:110-115 ("just for summary")
+            "x": torch.zeros(2, self.num_views, 3, 256, 256), "bbox": torch.zeros(2, self.num_views, 4),
+            "cam_params": {"intrinsic": torch.zeros(2, self.num_views, 4), "extrinsic": torch.zeros(2, self.num_views, 4, 4)}}
+        # the reference constructor random-initialises; ours does so deterministically
+        self._weights: "OrderedDict[str, np.ndarray]" = synth_state_dict(self.cfg, init_seed)
+        self._engines: Dict[tuple, ctypes.c_void_p] = {}
+        self._capture = False
+        self._profiling = False
+        self._last_key: Optional[tuple] = None
+
+    # ------------------------------------------------------------------ Lightning-style protocol
+    def freeze(self):
+        return self.eval()
+
+    def state_dict(self, *args, **kwargs):  # noqa: D401 - mirrors nn.Module.state_dict
+        return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._weights.items())
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """eval.py:27-52 semantics: legacy keys are remapped, strict=True raises on any
+        missing/unexpected key or shape mismatch (same message style as torch)."""
+        sd = remap_legacy_keys(state_dict)
+        layout = state_dict_layout(self.cfg)
+        missing = [k for k in layout if k not in sd]
+        unexpected = [k for k in sd if k not in layout]
+        errs = []
+        for k, shape in layout.items():
+            if k in sd and tuple(_np(sd[k]).shape) != tuple(shape):
+                errs.append(f"size mismatch for {k}: copying a param with shape {tuple(_np(sd[k]).shape)} from checkpoint, "
+                            f"the shape in current model is {tuple(shape)}.")
+        if strict and (missing or unexpected):
+            if unexpected:
+                errs.insert(0, "Unexpected key(s) in state_dict: " + ", ".join(f'"{k}"' for k in unexpected) + ".")
+            if missing:
+                errs.insert(0, "Missing key(s) in state_dict: " + ", ".join(f'"{k}"' for k in missing) + ".")
+        if errs:
+            raise RuntimeError("Error(s) in loading state_dict for HandMvNet:\n\t" + "\n\t".join(errs))
+        for k in layout:
+            if k in sd:
+                a = _np(sd[k])
+                self._weights[k] = a.astype(np.int64) if k.endswith("num_batches_tracked") else \
+                    np.ascontiguousarray(a, dtype=np.float32)
+        self._drop_engines()
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    # ------------------------------------------------------------------ engine management
+    def _drop_engines(self):
+        if self._engines:
+            lib = _lib.load()
+            for h in self._engines.values():
+                lib.hmv_destroy(h)
+        self._engines = {}
+
+    def __del__(self):
+        try:
+            self._drop_engines()
+        except Exception:
+            pass
+
+    def _engine(self, height: int, width: int, device_index: int):
+        key = (height, width, device_index)
+        if key in self._engines:
+            return self._engines[key]
+        lib = _lib.load()
+        cfg = self.cfg
+        c = _lib.HmvConfig()
+        c.struct_size = ctypes.sizeof(_lib.HmvConfig)
+        c.backbone = BACKBONE_IDS[cfg.backbone_type]
+        c.n_levels = len(cfg.backbone_channels)
+        for i, ch in enumerate(cfg.backbone_channels):
+            c.channels[i] = ch
+        c.num_views, c.height, c.width = cfg.num_views, height, width
+        c.image_size, c.heatmap_size = cfg.image_size, cfg.heatmap_size
+        c.pos_enc, c.fusion_layers, c.decoder = cfg.pos_mask, cfg.fusion_layers, int(cfg.use_gcn)
+        c.dtype, c.device = 0, device_index
+        h = ctypes.c_void_p()
+        _lib.check(lib.hmv_create(ctypes.byref(c), ctypes.byref(h)))
+        try:
+            for k in executed_keys(cfg):
+                a = np.ascontiguousarray(self._weights[k], dtype=np.float32)
+                shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+                _lib.check(lib.hmv_set_tensor(h, k.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim), h)
+            _lib.check(lib.hmv_finalize_weights(h), h)
+            lib.hmv_set_capture(h, int(self._capture))
+            lib.hmv_set_profiling(h, int(self._profiling))
+        except Exception:
+            lib.hmv_destroy(h)
+            raise
+        self._engines[key] = h
+        return h
+
+    def reserve(self, batch: int, height: int, width: int, device=None):
+        """Pre-allocates the workspace (keeps hipMalloc out of a timed region)."""
+        dev = torch.device(device if device is not None else "cuda")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        h = self._engine(height, width, idx)
+        _lib.check(_lib.load().hmv_reserve(h, batch), h)
+        return int(_lib.load().hmv_workspace_bytes(h, batch))
+
+    # ------------------------------------------------------------------ forward (handmvnet.py:158-266)
+    def forward(self, x, bbox=None, cam_params=None):
+        if not isinstance(x, torch.Tensor) or x.dim() != 5:
+            raise ValueError("x must be a [b, v, 3, h, w] tensor")
+        if not x.is_cuda:
+            raise _lib.HandMvError("handmvnet_amd runs on MI355X only: x must be a CUDA(HIP) tensor (no CPU fallback)")
+        b, v, c, hh, ww = x.shape
+        if c != 3:
+            raise ValueError("x must have 3 channels")
+        n = b * v
+        if n % self.num_views:
+            # the reference's .view(-1, num_views, ...) (handmvnet.py:194) raises here as well
+            raise RuntimeError(f"shape '[-1, {self.num_views}, ...]' is invalid for input of {n} frames")
+        batch = n // self.num_views
+        dev = x.device
+        x = x.contiguous().float()
+        need_cam = "crop" in self.cfg.pos_enc
+        bb = it = None
+        if need_cam:
+            if bbox is None or cam_params is None:
+                raise TypeError("pos_enc contains 'crop': bbox and cam_params['intrinsic'] are required")
+            bb = bbox.to(dev).reshape(-1, 4).contiguous().float()
+            it = cam_params["intrinsic"].to(dev).reshape(-1, 4).contiguous().float()
+            if bb.shape[0] != n or it.shape[0] != n:
+                raise RuntimeError("bbox / intrinsic must hold one row per frame")
+        h = self._engine(hh, ww, dev.index if dev.index is not None else torch.cuda.current_device())
+        hs_h, hs_w = hh // 8, ww // 8
+        out_crop = torch.empty(batch, self.num_views, 21, 2, device=dev, dtype=torch.float32)
+        out_cam = torch.empty(batch, 21, 3, device=dev, dtype=torch.float32)
+        out_hm = torch.empty(batch, self.num_views, 21, hs_h, hs_w, device=dev, dtype=torch.float32)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            rc = _lib.load().hmv_forward(h, batch, x.data_ptr(), bb.data_ptr() if bb is not None else None,
+                                         it.data_ptr() if it is not None else None, out_crop.data_ptr(), out_cam.data_ptr(),
+                                         out_hm.data_ptr(), ctypes.c_void_p(stream))
+        _lib.check(rc, h)
+        self._last_key = (hh, ww, dev.index if dev.index is not None else torch.cuda.current_device(), batch)
+        return {"joints_crop_img": out_crop, "joints_cam": out_cam, "heatmap": out_hm}
+
+    # ------------------------------------------------------------------ introspection (tests / bench)
+    def capture_stages(self, enable: bool = True):
+        self._capture = bool(enable)
+        for h in self._engines.values():
+            _lib.load().hmv_set_capture(h, int(enable))
+
+    def read_stage(self, name: str) -> torch.Tensor:
+        hh, ww, idx, batch = self._last_key
+        h = self._engines[(hh, ww, idx)]
+        n, d, cfg = batch * self.num_views, self.feat_dim, self.cfg
+        fdiv = 8 if cfg.is_paper else 16
+        shape = {"feat0": (n, cfg.backbone_channels[0], hh // fdiv, ww // fdiv), "coords_hm": (n, 21, 2),
+                 "tokens": (batch, self.num_views * 21, d), "fused": (batch, 21, d)}[name]
+        out = torch.empty(shape, device=f"cuda:{idx}", dtype=torch.float32)
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        _lib.check(_lib.load().hmv_read_stage(h, name.encode(), out.data_ptr(), out.numel(), ctypes.c_void_p(stream)), h)
+        return out
+
+    def set_profiling(self, enable: bool = True):
+        self._profiling = bool(enable)
+        for h in self._engines.values():
+            _lib.load().hmv_set_profiling(h, int(enable))
+
+    def profile_records(self):
+        """Per-launch records of the last forward (caller must have synchronised)."""
+        hh, ww, idx, _ = self._last_key
+        h = self._engines[(hh, ww, idx)]
+        lib = _lib.load()
+        recs = []
+        for i in range(lib.hmv_profile_count(h)):
+            name, label = ctypes.c_char_p(), ctypes.c_char_p()
+            ms, fl = ctypes.c_float(), ctypes.c_double()
+            _lib.check(lib.hmv_profile_get(h, i, ctypes.byref(name), ctypes.byref(label), ctypes.byref(ms), ctypes.byref(fl)), h)
+            recs.append({"kernel": name.value.decode(), "layer": label.value.decode(), "ms": ms.value, "flops": fl.value})
+        return recs

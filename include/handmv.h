@@ -1,0 +1,125 @@
+/*
+ * handmv.h -- C ABI of libhandmv.so, the MI355X-native (gfx950) HandMvNet inference engine.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference has no FFI
+ * layer of its own; the boundary it exposes is the Python object protocol of
+ *   HandMvNet(train_params, model_params, data_params)      /root/reference/src/models/handmvnet.py:28
+ *   HandMvNet.forward(x, bbox=None, cam_params=None)->dict  /root/reference/src/models/handmvnet.py:158-266
+ *   load_state_dict(state_dict, strict=True)                /root/reference/src/eval.py:46,50
+ * handmvnet_amd/model.py mirrors that protocol and binds the entry points below through
+ * ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions: plain C types only; integer status codes (0 = HMV_OK); no exceptions cross
+ * the ABI; the caller owns every input/output buffer, the engine owns weights + workspace;
+ * hmv_forward is asynchronous on the stream it is given (caller synchronises); a handle
+ * is bound to one device and is not re-entrant; different handles are independent.
+ */
+#ifndef HANDMV_H
+#define HANDMV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hmv_engine *hmv_handle;
+
+enum { HMV_OK = 0, HMV_ERR_ARG = 1, HMV_ERR_STATE = 2, HMV_ERR_MISSING_TENSOR = 3, HMV_ERR_SHAPE = 4, HMV_ERR_HIP = 5,
+       HMV_ERR_UNSUPPORTED = 6 };
+
+/* model_params["backbone_type"]: "18" | "34" | "50_paper"   (handmvnet.py:60-61) */
+enum { HMV_RESNET18 = 0, HMV_RESNET34 = 1, HMV_RESNET50_PAPER = 2 };
+/* model_params["pos_enc"] subset of {pos2d, crop, sin}       (handmvnet.py:89-95) */
+enum { HMV_POS2D = 1, HMV_POS_CROP = 2, HMV_POS_SIN = 4 };
+/* model_params["use_gcn"]: JointsDecoderNN | JointsDecoderGCN (handmvnet.py:152-155) */
+enum { HMV_DECODER_NN = 0, HMV_DECODER_GCN = 1 };
+enum { HMV_F32 = 0 };
+
+typedef struct hmv_config {
+    int32_t struct_size;   /* sizeof(hmv_config), ABI guard */
+    int32_t backbone;      /* HMV_RESNET* */
+    int32_t n_levels;      /* len(model_params["backbone_channels"]) */
+    int32_t channels[4];   /* model_params["backbone_channels"], last backbone level first */
+    int32_t num_views;     /* model_params["num_views"] */
+    int32_t height, width; /* frame size the plan is built for (x.shape[-2:]) */
+    int32_t image_size;    /* data_params["image_size"]   -- config constant, handmvnet.py:252 */
+    int32_t heatmap_size;  /* data_params["heatmap_size"] -- config constant, handmvnet.py:252 */
+    int32_t pos_enc;       /* bitmask of HMV_POS* */
+    int32_t fusion_layers; /* model_params["fusion_layers"], odd */
+    int32_t decoder;       /* HMV_DECODER_* */
+    int32_t dtype;         /* HMV_F32 */
+    int32_t device;        /* HIP device ordinal */
+} hmv_config;
+
+/* Replaces HandMvNet.__init__ (handmvnet.py:28-125): validates the configuration and
+ * builds the layer plan; no weights yet. */
+int hmv_create(const hmv_config *cfg, hmv_handle *out);
+
+/* Replaces one entry of load_state_dict (eval.py:46,50): `key` is the reference's
+ * state_dict key, `host` fp32 data in the reference's layout (OIHW convs, [out,in]
+ * linears, ...), copied.  Unknown keys (layer4.*, fc.*) are accepted and ignored. */
+int hmv_set_tensor(hmv_handle h, const char *key, const float *host, const int64_t *shape, int32_t ndim);
+
+/* After the last hmv_set_tensor: checks every key the forward reads is present with the
+ * right shape (HMV_ERR_MISSING_TENSOR / HMV_ERR_SHAPE name the key in hmv_last_error),
+ * folds BatchNorm into conv scale/bias, repacks to the MFMA-friendly K-major layout and
+ * uploads.  Replaces .to(device).eval().freeze() (eval_fps.py:63-65). */
+int hmv_finalize_weights(hmv_handle h);
+
+/* Bytes of device workspace a forward of `batch` multi-view samples needs. */
+size_t hmv_workspace_bytes(hmv_handle h, int32_t batch);
+
+/* (Re)allocates the workspace for up to `batch` samples.  hmv_forward calls it on demand;
+ * call it up front to keep allocation out of a timed or graph-captured region. */
+int hmv_reserve(hmv_handle h, int32_t batch);
+
+/* Replaces HandMvNet.forward (handmvnet.py:158-266).  All pointers are DEVICE pointers.
+ *   x               [B][V][3][H][W] fp32 (the reference's NCHW frames)
+ *   bbox            [B][V][4]  (x1,y1,x2,y2), may be NULL unless HMV_POS_CROP
+ *   intrinsic       [B][V][4]  (fx,fy,cx,cy), may be NULL unless HMV_POS_CROP
+ *   joints_crop_img [B][V][21][2]  out
+ *   joints_cam      [B][21][3]     out
+ *   heatmap         [B][V][21][H/8][W/8] out, may be NULL (skips the NCHW copy)
+ *   stream          hipStream_t (NULL = default stream) */
+int hmv_forward(hmv_handle h, int32_t batch, const float *x, const float *bbox, const float *intrinsic,
+                float *joints_crop_img, float *joints_cam, float *heatmap, void *stream);
+
+/* Human-readable description of the last failure on this handle (or on creation when h is NULL). */
+const char *hmv_last_error(hmv_handle h);
+
+void hmv_destroy(hmv_handle h);
+
+/* ---- introspection used by tests and bench.py (not part of the reference's surface) ---- */
+
+/* Copies an intermediate of the LAST forward to a device buffer, converted to the
+ * reference's layout.  stage: "feat0" [N][C][h][w], "coords_hm" [N][21][2],
+ * "tokens" [B][V*21][d] (before the sinusoidal PE is added), "fused" [B][21][d].
+ * Stage capture must have been enabled before that forward. */
+int hmv_set_capture(hmv_handle h, int32_t enable);
+int hmv_read_stage(hmv_handle h, const char *stage, float *dst_device, size_t capacity_floats, void *stream);
+
+/* Per-launch timing with hipEvents on the forward's stream (0 = off, 1 = on).  When on,
+ * hmv_forward records an event pair around every kernel launch of the conv/GEMM kernel
+ * family; records accumulate over successive forwards (calling hmv_set_profiling again
+ * clears them); hmv_profile_* read them back after the caller has synchronised the stream. */
+int hmv_set_profiling(hmv_handle h, int32_t enable);
+int hmv_profile_count(hmv_handle h);
+/* name: kernel symbol family ("conv_igemm_f32<128x128>" ...); label: layer ("layer3.2.conv2");
+ * ms: duration; flops: algorithmic 2*M*N*K of that launch. */
+int hmv_profile_get(hmv_handle h, int32_t index, const char **name, const char **label, float *ms, double *flops);
+
+/* One NHWC convolution through the engine's conv kernel (op-level parity tests).
+ * in [N][H][W][Cin] device; weight OIHW host (Cin must be a multiple of 4);
+ * bias host[Cout] or NULL; residual device [N][Ho][Wo][Cout] or NULL; out device NHWC. */
+int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                  const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S,
+                  int32_t stride, int32_t pad, const float *residual, int32_t relu, float *out, void *stream);
+
+const char *hmv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HANDMV_H */

@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--per-layer", default="", help="write per-layer launch timings (JSON) to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,6 +157,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if rank == 0 and args.per_layer:
+        lay = {}
+        for r in recs:
+            e = lay.setdefault(r["layer"], {"kernel": r["kernel"], "ms": 0.0, "flops": r["flops"], "n": 0})
+            e["ms"] += r["ms"]; e["n"] += 1
+        rows = [{"layer": k, "kernel": v["kernel"], "avg_ms": v["ms"] / v["n"], "gflop": v["flops"] / 1e9,
+                 "tflops": v["flops"] / (v["ms"] / v["n"] * 1e-3) / 1e12} for k, v in lay.items()]
+        with open(args.per_layer, "w") as f:
+            json.dump(rows, f, indent=1)
     if rank == 0:
         # ---- roofline of the dominant kernel from the live per-launch event timings
         fam = {}

@@ -34,12 +34,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-template <int BM, int BN, int WGM, int WGN, bool SMALLC>
+// 256 bytes of zeros: out-of-range taps / rows read from here, so that the global load result
+// needs no post-processing and its s_waitcnt can sink below the MFMAs to the LDS write.
+static float *g_zero_page = nullptr;
+static hipError_t ensure_zero_page() {
+    if (g_zero_page) return hipSuccess;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&g_zero_page), 256);
+    if (e == hipSuccess) e = hipMemset(g_zero_page, 0, 256);
+    return e;
+}
+
+// GENERIC = false: the backbone's epilogue (bias, optional residual, optional ReLU, rows written in
+// place).  GENERIC = true adds the rarely used paths (sub-pixel output scatter, residual row remap,
+// GELU / LeakyReLU); keeping them out of the hot instantiation keeps its epilogue straight-line.
+template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool GENERIC>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int AP = BM / 32, BP = BN / 32;
+    constexpr int LDC = BN + 4;  // epilogue staging row stride (floats)
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile is made of 32x32 MFMA blocks");
+    static_assert(BM * LDC <= 2 * (BM + BN) * LDS_LD, "epilogue staging must fit in the tile buffers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sA = smem;                    // [2][BM][LDS_LD]
     float *sB = smem + 2 * BM * LDS_LD;  // [2][BN][LDS_LD]
@@ -61,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     // ---- per-thread gather roles: 8 threads cover one 32-float k-row segment
     const int lrow = tid >> 3, kq = tid & 7;
     const float *abase[AP];
-    int hi0[AP], wi0[AP];
+    int hi0[AP], wi0[AP], aoff[AP];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
@@ -73,6 +88,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
         abase[i] = p.in + (size_t)n * p.H * p.W * p.Cin;
         hi0[i] = ok ? ho * p.stride - p.pad_h : -(1 << 28);  // out-of-range rows fail the bounds test
         wi0[i] = wo * p.stride - p.pad_w;
+        aoff[i] = ok ? (hi0[i] * p.W + wi0[i]) * p.Cin + (SMALLC ? 0 : 4 * kq) : 0;
     }
     const float *wrow[BP];
 #pragma unroll
@@ -88,29 +104,28 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
 
     f32x4 ra[AP], rb[BP];
     const int nk = p.Kpad / BK;
+    const float *zero = p.zero;
 
 #define HMV_LOAD_TILE(kt)                                                                         \
     {                                                                                             \
         const int k0 = (kt) * BK;                                                                 \
-        int r_, s_, coff_;                                                                        \
-        if (!SMALLC) {                                                                            \
+        int r_, s_, delta_;                                                                       \
+        if (!SMALLC) { /* the (r, s) tap of a k-step is wave-uniform scalar work */               \
             const int tap = k0 / p.Cin;                                                           \
             r_ = tap / p.S;                                                                       \
             s_ = tap - r_ * p.S;                                                                  \
-            coff_ = k0 - tap * p.Cin + 4 * kq;                                                    \
+            delta_ = (r_ * p.W + s_) * p.Cin + (k0 - tap * p.Cin);                                \
         } else { /* Cin == 4: one tap per 16-byte vector */                                       \
             const int tap = (k0 >> 2) + kq;                                                       \
             r_ = tap / p.S;                                                                       \
             s_ = tap - r_ * p.S;                                                                  \
-            coff_ = 0;                                                                            \
             if (tap >= p.R * p.S) r_ = 1 << 28;                                                   \
+            delta_ = (r_ * p.W + s_) * 4;                                                         \
         }                                                                                         \
         _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                          \
-            const int hi = hi0[i] + r_, wi = wi0[i] + s_;                                         \
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;         \
-            const float *src = abase[i] + (ok ? (hi * p.W + wi) * p.Cin + coff_ : 0);             \
-            f32x4 v = *reinterpret_cast<const f32x4 *>(src);                                      \
-            ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};                                           \
+            const bool ok = (unsigned)(hi0[i] + r_) < (unsigned)p.H && (unsigned)(wi0[i] + s_) < (unsigned)p.W; \
+            const float *src = ok ? abase[i] + (aoff[i] + delta_) : zero;                         \
+            ra[i] = *reinterpret_cast<const f32x4 *>(src);                                        \
         }                                                                                         \
         _Pragma("unroll") for (int i = 0; i < BP; ++i) rb[i] =                                    \
             *reinterpret_cast<const f32x4 *>(wrow[i] + k0);                                       \
@@ -155,38 +170,95 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
 #undef HMV_LOAD_TILE
 #undef HMV_STORE_TILE
 
-    // ---- fused epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float bcol[TN];
-    int col[TN];
+    // ---- fused epilogue, staged through LDS so that global traffic is 16-byte vectors on full rows.
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    float *sC = smem;  // [BM][LDC]; the tile buffers are dead after the loop's last barrier
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        col[b] = nt * BN + wn * WN + b * 32 + l31;
-        bcol[b] = p.bias[col[b]];  // bias buffer is padded to the weight rows
-    }
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = mt * BM + wm * WM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            if (m >= p.M) continue;
-            size_t orow = (size_t)m;
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * WM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                sC[row * LDC + wn * WN + b * 32 + l31] = acc[a][b][e];
+            }
+    __syncthreads();
+
+    const int m0 = mt * BM, n0 = nt * BN;
+    const bool vec = ((p.ldc & 3) == 0) && (p.res == nullptr || (p.ldr & 3) == 0);
+    if (vec) {
+        constexpr int TPR = BN / 4;          // threads per row
+        constexpr int RPP = 256 / TPR;       // rows per pass
+        constexpr int NPASS = BM / RPP;
+        constexpr int UB = NPASS < 4 ? NPASS : 4;  // rows in flight per thread
+        const int c4 = tid % TPR, r0 = tid / TPR;
+        const int col = n0 + 4 * c4;
+        // columns [Cout, round4(Cout)) hold exact zeros (zero-padded weights and bias): writing them is
+        // harmless whenever the row stride leaves room, which lets Cout = 21 use vector stores too.
+        const int cend = p.Cout + 3 < p.ldc ? ((p.Cout + 3) & ~3) : p.ldc;
+        if (col < cend) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + col);
+            const bool has_res = p.res != nullptr;
+            const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+#pragma unroll
+            for (int g = 0; g < NPASS; g += UB) {
+                f32x4 v[UB], rv[UB];
+                size_t orow[UB];
+                bool okr[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int r = r0 + (g + u) * RPP, m = m0 + r;
+                    okr[u] = m < p.M;
+                    orow[u] = (size_t)m;
+                    size_t rrow = (size_t)m;
+                    if (GENERIC) {
+                        if (p.scatter) {
+                            const int n = m / HoWo, rem = m - n * HoWo;
+                            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                            orow[u] = ((size_t)n * (p.Ho * p.osy) + (ho * p.osy + p.ooy)) * (size_t)(p.Wo * p.osx) + (wo * p.osx + p.oox);
+                        }
+                        if (p.rg_out) rrow = (size_t)(m / p.rg_out) * p.rg_in + (m % p.rg_out);
+                    }
+                    const float *rp = (has_res && okr[u]) ? p.res + rrow * p.ldr + col : zero;
+                    rv[u] = *reinterpret_cast<const f32x4 *>(rp);
+                    v[u] = *reinterpret_cast<const f32x4 *>(&sC[r * LDC + 4 * c4]);
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    f32x4 t = v[u] + bv + rv[u];
+                    if (GENERIC) {
+                        if (p.act == ACT_GELU) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) t[j] = 0.5f * t[j] * (1.f + erff(t[j] * 0.70710678118654752440f));
+                        } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) t[j] = t[j] > 0.f ? t[j] : 0.01f * t[j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], lo);
+                    if (okr[u]) *reinterpret_cast<f32x4 *>(p.out + orow[u] * p.ldc + col) = t;
+                }
+            }
+        }
+    } else if (GENERIC) {  // scalar fallback (row strides that are not multiples of 4, e.g. the 21x3 output)
+        for (int idx = tid; idx < BM * BN; idx += 256) {
+            const int r = idx / BN, c = idx - r * BN;
+            const int m = m0 + r, col = n0 + c;
+            if (m >= p.M || col >= p.Cout) continue;
+            size_t orow = (size_t)m, rrow = (size_t)m;
             if (p.scatter) {
                 const int n = m / HoWo, rem = m - n * HoWo;
                 const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
                 orow = ((size_t)n * (p.Ho * p.osy) + (ho * p.osy + p.ooy)) * (size_t)(p.Wo * p.osx) + (wo * p.osx + p.oox);
             }
-            size_t rrow = (size_t)m;
             if (p.rg_out) rrow = (size_t)(m / p.rg_out) * p.rg_in + (m % p.rg_out);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                if (col[b] >= p.Cout) continue;
-                float v = acc[a][b][e] + bcol[b];
-                if (p.res) v += p.res[rrow * p.ldr + col[b]];
-                if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
-                else if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-                else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-                p.out[orow * p.ldc + col[b]] = v;
-            }
+            float v = sC[r * LDC + c] + p.bias[col];
+            if (p.res) v += p.res[rrow * p.ldr + col];
+            if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+            else if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+            else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+            p.out[orow * p.ldc + col] = v;
         }
     }
 }
@@ -209,17 +281,22 @@ ConvTile conv_pick_tile(int M, int Cout) {
     return TILE_128x32;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SMALLC>
+template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool GENERIC>
 static hipError_t launch_one(ConvParams p, hipStream_t s) {
     static bool configured = false;
     const size_t lds = 2ull * (BM + BN) * LDS_LD * sizeof(float);
-    auto kern = conv_igemm_f32<BM, BN, WGM, WGN, SMALLC>;
+    auto kern = conv_igemm_f32<BM, BN, WGM, WGN, SMALLC, GENERIC>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = true;
     }
+    {
+        hipError_t e = ensure_zero_page();
+        if (e != hipSuccess) return e;
+    }
+    p.zero = g_zero_page;
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.Cout + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(256), lds, s, p);
@@ -228,15 +305,20 @@ static hipError_t launch_one(ConvParams p, hipStream_t s) {
 
 hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s) {
     if (p.M <= 0) return hipSuccess;
+    const bool generic = p.scatter || p.rg_out || p.act == ACT_GELU || p.act == ACT_LEAKY || (p.ldc & 3) ||
+                         (p.res && (p.ldr & 3));
     if (p.Cin < BK) {  // stem: Cin == 4
-        if (p.Cin != 4) return hipErrorInvalidValue;
-        return launch_one<128, 64, 2, 2, true>(p, s);
+        if (p.Cin != 4 || generic) return hipErrorInvalidValue;
+        return launch_one<128, 64, 2, 2, true, false>(p, s);
     }
     if (p.Cin % BK != 0) return hipErrorInvalidValue;
     switch (tile) {
-        case TILE_128x128: return launch_one<128, 128, 2, 2, false>(p, s);
-        case TILE_128x64: return launch_one<128, 64, 2, 2, false>(p, s);
-        default: return launch_one<128, 32, 4, 1, false>(p, s);
+        case TILE_128x128:
+            return generic ? launch_one<128, 128, 2, 2, false, true>(p, s) : launch_one<128, 128, 2, 2, false, false>(p, s);
+        case TILE_128x64:
+            return generic ? launch_one<128, 64, 2, 2, false, true>(p, s) : launch_one<128, 64, 2, 2, false, false>(p, s);
+        default:
+            return generic ? launch_one<128, 32, 4, 1, false, true>(p, s) : launch_one<128, 32, 4, 1, false, false>(p, s);
     }
 }
 

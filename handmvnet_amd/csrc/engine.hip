@@ -7,6 +7,7 @@
 // entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -338,7 +339,7 @@ int hmv_set_tensor(hmv_handle h, const char *key, const float *host, const int64
 int hmv_finalize_weights(hmv_handle h) {
     if (!h) return HMV_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    for (void *p : h->dev_allocs) hipFree(p);
+    for (void *p : h->dev_allocs) (void)hipFree(p);
     h->dev_allocs.clear();
     for (auto &v : h->blocks) v.clear();
     h->attn.clear();
@@ -503,6 +504,57 @@ int hmv_finalize_weights(hmv_handle h) {
     HIPCHK(h, hipDeviceSynchronize());
     h->finalized = true;
     h->host.clear();  // host copies are no longer needed
+    return HMV_OK;
+}
+
+
+// Diagnostic: time `iters` launches of one conv shape with a chosen tile (tile < 0: engine's choice).
+int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t R, int32_t S,
+                   int32_t stride, int32_t pad, int32_t with_residual, int32_t tile, int32_t iters, float *avg_ms) {
+    if (hipSetDevice(device) != hipSuccess) return HMV_ERR_HIP;
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    const int K = R * S * Cin, Kpad = round_up(K, 32), Cp = round_up(Cout, 128);
+    const size_t nin = (size_t)N * H * W * Cin, nout = (size_t)N * Ho * Wo * Cout, nw = (size_t)Cp * Kpad;
+    float *din = nullptr, *dout = nullptr, *dw = nullptr, *db = nullptr, *dres = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&din), nin * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dout), nout * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dw), nw * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&db), (size_t)Cp * 4);
+    if (e == hipSuccess && with_residual) e = hipMalloc(reinterpret_cast<void **>(&dres), nout * 4);
+    if (e == hipSuccess) {
+        // pseudo-random (not zero: zero operands raise the clock and flatter the number)
+        std::vector<float> hbuf(std::max(std::max(nin, nw), with_residual ? nout : (size_t)1));
+        uint32_t st = 12345u;
+        auto fill = [&](float *d, size_t n) {
+            for (size_t i = 0; i < n; ++i) { st = st * 1664525u + 1013904223u; hbuf[i] = ((st >> 8) * (1.0f / 8388608.0f)) - 1.0f; }
+            return hipMemcpy(d, hbuf.data(), n * 4, hipMemcpyHostToDevice);
+        };
+        e = fill(din, nin);
+        if (e == hipSuccess) e = fill(dw, nw);
+        if (e == hipSuccess && with_residual) e = fill(dres, nout);
+        if (e == hipSuccess) e = hipMemset(db, 0, (size_t)Cp * 4);
+    }
+    if (e == hipSuccess) {
+        ConvParams p{};
+        p.in = din; p.wgt = dw; p.bias = db; p.res = dres; p.out = dout;
+        p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
+        p.R = R; p.S = S; p.stride = stride; p.pad_h = pad; p.pad_w = pad; p.K = K; p.Kpad = Kpad;
+        p.M = N * Ho * Wo; p.ldc = Cout; p.ldr = Cout; p.act = ACT_RELU; p.osy = p.osx = 1;
+        const ConvTile t = tile < 0 ? conv_pick_tile(p.M, Cout) : (ConvTile)tile;
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_conv(p, t, nullptr);
+        if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+        for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_conv(p, t, nullptr);
+        if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (avg_ms) *avg_ms = ms / (float)iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    for (float *ptr : {din, dout, dw, db, dres}) if (ptr) hipFree(ptr);
+    if (e != hipSuccess) { g_create_err = std::string("hmv_bench_conv: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
     return HMV_OK;
 }
 
@@ -766,7 +818,7 @@ int ensure_capture(hmv_engine *h, int B) {
     const int N = B * c.num_views;
     const int fdiv = h->paper ? 8 : 16;
     for (float **p : {&h->cap_feat0, &h->cap_coords, &h->cap_tokens, &h->cap_fused}) {
-        if (*p) hipFree(*p);
+        if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
     h->cap_feat0_n = (size_t)N * c.channels[0] * (c.height / fdiv) * (c.width / fdiv);
@@ -834,13 +886,13 @@ int hmv_forward(hmv_handle h, int32_t batch, const float *x, const float *bbox, 
 
 void hmv_destroy(hmv_handle h) {
     if (!h) return;
-    hipSetDevice(h->cfg.device);
-    hipDeviceSynchronize();
-    for (void *p : h->dev_allocs) hipFree(p);
-    if (h->arena) hipFree(h->arena);
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void *p : h->dev_allocs) (void)hipFree(p);
+    if (h->arena) (void)hipFree(h->arena);
     for (float *p : {h->cap_feat0, h->cap_coords, h->cap_tokens, h->cap_fused})
-        if (p) hipFree(p);
-    for (auto &r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+        if (p) (void)hipFree(p);
+    for (auto &r : h->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     delete h;
 }
 
@@ -920,8 +972,8 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
         e = launch_conv(p, conv_pick_tile(p.M, Cout), static_cast<hipStream_t>(stream));
         if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
     }
-    if (dw) hipFree(dw);
-    if (db) hipFree(db);
+    if (dw) (void)hipFree(dw);
+    if (db) (void)hipFree(db);
     if (e != hipSuccess) { g_create_err = std::string("hmv_op_conv2d: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
     return HMV_OK;
 }

@@ -28,6 +28,7 @@ struct ConvParams {
     int scatter;        // output pixel (ho*osy + ooy, wo*osx + oox) in an (Ho*osy) x (Wo*osx) image
     int osy, osx, ooy, oox;
     int mtiles, ntiles;
+    const float *zero;  // 256 bytes of zeros (filled in by launch_conv)
 };
 
 enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_COUNT = 3 };

@@ -67,6 +67,14 @@ int hmvo_num_threads(void) {
 #endif
 }
 
+void hmvo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int hmvo_acc_is_double(void) { return (int)(sizeof(acc_t) == 8); }
 
 void hmvo_clear(void) {

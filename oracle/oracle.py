@@ -34,6 +34,31 @@ def build(force: bool = False) -> None:
 _LIBS: Dict[str, ctypes.CDLL] = {}
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: min(affinity mask, cgroup cpu quota).  An OpenMP team
+    sized by the host's core count on a box that grants a 16-CPU share just thrashes."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, q // int(g.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit():
+        n = min(n, int(env)) if int(env) > 0 else n
+    return max(1, n)
+
+
 def _lib(acc: str) -> ctypes.CDLL:
     if acc not in ("f32", "f64"):
         raise ValueError(acc)
@@ -44,6 +69,7 @@ def _lib(acc: str) -> ctypes.CDLL:
         lib = ctypes.CDLL(path)
         lib.hmvo_last_error.restype = ctypes.c_char_p
         lib.hmvo_forward.restype = ctypes.c_int
+        lib.hmvo_set_num_threads(min(usable_cpus(), 64))
         _LIBS[acc] = lib
     return _LIBS[acc]
 

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -230,7 +231,7 @@ struct Loader {
         L.label = label;
         L.Cin = Cin; L.Cout = Cout; L.R = R; L.S = S; L.K = K;
         L.Kpad = round_up(K, 32);
-        L.Cout_pad = round_up(Cout, 128);
+        L.Cout_pad = round_up(Cout, 256);
         if (rc != HMV_OK) return;
         std::vector<float> w((size_t)L.Cout_pad * L.Kpad, 0.f), b((size_t)L.Cout_pad, 0.f);
         for (int o = 0; o < Cout; ++o) {
@@ -513,8 +514,10 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
                    int32_t stride, int32_t pad, int32_t with_residual, int32_t tile, int32_t iters, float *avg_ms) {
     if (hipSetDevice(device) != hipSuccess) return HMV_ERR_HIP;
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
-    const int K = R * S * Cin, Kpad = round_up(K, 32), Cp = round_up(Cout, 128);
-    const size_t nin = (size_t)N * H * W * Cin, nout = (size_t)N * Ho * Wo * Cout, nw = (size_t)Cp * Kpad;
+    const int K = R * S * Cin, Kpad = round_up(K, 32), Cp = round_up(Cout, 256);
+    const char *ea = getenv("HMV_BENCH_APAD"), *ew = getenv("HMV_BENCH_WPAD");
+    const int lda = Cin + (ea ? atoi(ea) : 0), ldw = Kpad + (ew ? atoi(ew) : 0);
+    const size_t nin = (size_t)N * H * W * lda, nout = (size_t)N * Ho * Wo * Cout, nw = (size_t)Cp * ldw;
     float *din = nullptr, *dout = nullptr, *dw = nullptr, *db = nullptr, *dres = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&din), nin * 4);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dout), nout * 4);
@@ -540,6 +543,14 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
         p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
         p.R = R; p.S = S; p.stride = stride; p.pad_h = pad; p.pad_w = pad; p.K = K; p.Kpad = Kpad;
         p.M = N * Ho * Wo; p.ldc = Cout; p.ldr = Cout; p.act = ACT_RELU; p.osy = p.osx = 1;
+        p.lda = lda; p.ldw = ldw;
+        unsigned long long *ddbg = nullptr;
+        const int nblk_dbg = ((p.M + 127) / 128) * ((Cout + 31) / 32);
+        if (getenv("HMV_BENCH_CLOCK")) {
+            (void)hipMalloc(reinterpret_cast<void **>(&ddbg), (size_t)nblk_dbg * 64);
+            (void)hipMemset(ddbg, 0, (size_t)nblk_dbg * 64);
+            p.dbg = ddbg;
+        }
         const ConvTile t = tile < 0 ? conv_pick_tile(p.M, Cout) : (ConvTile)tile;
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -551,6 +562,22 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
         float ms = 0.f;
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
         if (avg_ms) *avg_ms = ms / (float)iters;
+        if (ddbg) {
+            std::vector<unsigned long long> hd((size_t)nblk_dbg * 8);
+            (void)hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost);
+            if (const char *dump = getenv("HMV_BENCH_DUMP")) {
+                if (FILE *f = fopen(dump, "wb")) { fwrite(hd.data(), 8, hd.size(), f); fclose(f); }
+            }
+            std::vector<double> clk, cyc;
+            for (int i = 0; i < nblk_dbg; ++i)
+                if (hd[8 * i + 1] > 0) { clk.push_back((double)hd[8 * i] / (double)hd[8 * i + 1] * 0.1); cyc.push_back((double)hd[8 * i]); }
+            if (!clk.empty()) {
+                std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
+                fprintf(stderr, "[clock] blocks=%zu median %.3f GHz (p10 %.3f p90 %.3f), median main-loop cycles %.0f\n", clk.size(),
+                        clk[clk.size() / 2], clk[clk.size() / 10], clk[clk.size() * 9 / 10], cyc[cyc.size() / 2]);
+            }
+            (void)hipFree(ddbg);
+        }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     for (float *ptr : {din, dout, dw, db, dres}) if (ptr) hipFree(ptr);
@@ -947,7 +974,7 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
         return HMV_ERR_ARG;
     }
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
-    const int K = R * S * Cin, Kpad = round_up(K, 32), Cp = round_up(Cout, 128);
+    const int K = R * S * Cin, Kpad = round_up(K, 32), Cp = round_up(Cout, 256);
     std::vector<float> w((size_t)Cp * Kpad, 0.f), b((size_t)Cp, 0.f);
     for (int o = 0; o < Cout; ++o) {
         for (int k = 0; k < K; ++k) {

@@ -29,13 +29,13 @@ struct ConvParams {
     int osy, osx, ooy, oox;
     int mtiles, ntiles;
     const float *zero;  // 256 bytes of zeros (filled in by launch_conv)
-    int tune;           // development knobs (HMV_TUNE env)
     int lda;            // input pixel stride in floats (0 = Cin)
     int ldw;            // weight row stride in floats (0 = Kpad)
     unsigned long long *dbg;  // diagnostic builds only: per-block {shader cycles, 100 MHz ticks} of the main loop
 };
 
-enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_128x128_8W = 3, TILE_256x128_8W = 4, TILE_V3_128x128 = 5, TILE_V4_128x128 = 6, TILE_V4_256x128 = 7, TILE_V4_128x256 = 8, TILE_V4_256x256 = 9, TILE_V4_128x64 = 10, TILE_V4_128x32 = 11, TILE_COUNT = 12 };
+enum ConvTile { TILE_128x32 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x128 = 3, TILE_128x256 = 4, TILE_256x256 = 5,
+                TILE_COUNT = 6 };
 int conv_tile_bn(ConvTile t);                       // N-tile width of a tile config
 const char *conv_tile_name(ConvTile t, bool smallc);
 ConvTile conv_pick_tile(int M, int Cout);

@@ -6,9 +6,12 @@
 //
 //   out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] + residual[m][n] )
 //
-// M = images * Ho * Wo output pixels, N = Cout, K = R*S*Cin with k = (r, s, c) so that
-// consecutive k are consecutive NHWC channels.  The im2col matrix A is never built: every
-// lane of an LDS-DMA instruction supplies the global address of one 16-byte channel vector.
+// M = images * Ho * Wo output pixels, N = Cout, K = R*S*Cin.  K is ordered
+// (32-channel chunk, r, s, channel in chunk): a k-step is one tap of one 32-channel chunk, and the
+// R*S taps of a chunk are consecutive k-steps, so the shifted re-reads of a 3x3 window hit L1/L2
+// instead of re-streaming the activation from HBM once per tap (measured: FETCH_SIZE 4.3x the
+// algorithmic bytes with tap-major K).  The im2col matrix A is never built: every lane of an
+// LDS-DMA instruction supplies the global address of one 16-byte channel vector.
 //
 // MI355X mapping (the measurements behind each choice are in DESIGN.md section 4)
 //   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD): each wave owns a (32*TM)x(32*TN)
@@ -186,14 +189,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
             wptr[i] += BK;                                                                                  \
         }                                                                                                   \
         ck += BK;                                                                                           \
-        if (MODE == MODE_TAPS) {                                                                            \
-            cc += BK;                                                                                       \
-            cdelta += BK;                                                                                   \
-            if (cc >= p.Cin) { /* next tap: (r, s+1) or (r+1, 0) */                                         \
-                cc = 0;                                                                                     \
-                cdelta -= p.Cin;                                                                            \
-                if (++cs == p.S) { cs = 0; ++cr; cdelta += (p.W - p.S) * p.lda; }                           \
-                cdelta += p.lda;                                                                            \
+        if (MODE == MODE_TAPS) { /* K order: 32-channel chunk slowest, taps fastest (see ConvParams) */     \
+            cdelta += p.lda;                                                                                \
+            if (++cs == p.S) {                                                                              \
+                cs = 0;                                                                                     \
+                cdelta += (p.W - p.S) * p.lda;                                                              \
+                if (++cr == p.R) { cr = 0; cc += BK; cdelta = cc; }                                         \
             }                                                                                               \
         }                                                                                                   \
     }

@@ -257,7 +257,15 @@ struct Loader {
         const int cp = cin_pad ? cin_pad : Cin;
         const float *wd = w->data.data();
         auto wt = [=](int o, int k) -> float {
-            const int c = k % cp, tap = k / cp;
+            int c, tap;
+            if (cp >= 32) {   // K order (chunk, r, s, c % 32): conv_igemm.hip
+                const int chunk = k / (32 * R * S), rem = k % (32 * R * S);
+                tap = rem / 32;
+                c = chunk * 32 + rem % 32;
+            } else {          // the stem: (r, s, c)
+                c = k % cp;
+                tap = k / cp;
+            }
             if (c >= Cin) return 0.f;
             return wd[(((size_t)o * Cin + c) * R + tap / S) * S + tap % S];
         };
@@ -392,8 +400,9 @@ int hmv_finalize_weights(hmv_handle h) {
             for (int a = 0; a < 2; ++a)
                 for (int b = 0; b < 2; ++b) {
                     const float *wd = w->data.data();
-                    auto wt = [=](int o, int k) -> float {
-                        const int ci = k % c0, tap = k / c0, r = tap / 2, s = tap % 2;
+                    auto wt = [=](int o, int k) -> float {   // K order (chunk, r, s, c % 32)
+                        const int chunk = k / (32 * 4), rem = k % (32 * 4), tap = rem / 32;
+                        const int ci = chunk * 32 + rem % 32, r = tap / 2, s = tap % 2;
                         return wd[(((size_t)ci * 128 + o) * 4 + kmap[a][r]) * 4 + kmap[b][s]];
                     };
                     L.finish(h->deconv[a * 2 + b], "pose_net.0.phase" + std::to_string(a * 2 + b), c0, 128, 2, 2, 4 * c0, wt,
@@ -978,7 +987,9 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
     std::vector<float> w((size_t)Cp * Kpad, 0.f), b((size_t)Cp, 0.f);
     for (int o = 0; o < Cout; ++o) {
         for (int k = 0; k < K; ++k) {
-            const int c = k % Cin, tap = k / Cin;
+            int c, tap;
+            if (Cin >= 32) { const int chunk = k / (32 * R * S), rem = k % (32 * R * S); tap = rem / 32; c = chunk * 32 + rem % 32; }
+            else { c = k % Cin; tap = k / Cin; }
             w[(size_t)o * Kpad + k] = w_oihw[(((size_t)o * Cin + c) * R + tap / S) * S + tap % S];
         }
         if (bias_host) b[o] = bias_host[o];

@@ -9,11 +9,12 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_LEAKY = 3 };
 
 // Implicit-GEMM convolution / plain GEMM on fp32 MFMA.
 //   out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] + res[m'][n] )
-// A[m][k] is gathered on the fly from an NHWC tensor: m = (img, ho, wo), k = (r, s, c).
+// A[m][k] is gathered on the fly from an NHWC tensor: m = (img, ho, wo), k = (chunk, r, s, c % 32).
 // A plain row-major GEMM is the special case H = W = R = S = 1, N = M, Cin = K.
 struct ConvParams {
     const float *in;    // NHWC [N][H][W][Cin]
-    const float *wgt;   // [Cout_pad][Kpad], K ordered (r, s, c), zero padded
+    const float *wgt;   // [Cout_pad][Kpad], zero padded; K ordered (c / 32, r, s, c % 32) for Cin >= 32
+                        // and (r, s, c) for the 4-channel stem
     const float *bias;  // [Cout_pad] (folded BN shift + conv bias), never null
     const float *res;   // residual, row-major [M'][ldr] or null
     float *out;         // [M''][ldc]

@@ -37,11 +37,16 @@ def gather_outputs(local: Dict[str, torch.Tensor], total: Optional[int] = None, 
             full = torch.empty((n_local * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             dist.all_gather_into_tensor(full, t, group=group)
         else:
-            sizes = [shard_range(total, r, world) for r in range(world)]
-            assert sizes[rank][1] - sizes[rank][0] == n_local, "local shard does not match shard_range"
-            parts = [torch.empty((b - a,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for a, b in sizes]
-            dist.all_gather(parts, t, group=group)
-            full = torch.cat(parts, dim=0)
+            # ragged shards: pad every shard to the largest one so that ONE fixed-size all-gather does
+            # (works on RCCL and gloo alike), then keep each rank's valid rows
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[rank][1] - spans[rank][0] == n_local, "local shard does not match shard_range"
+            n_max = max(b_ - a_ for a_, b_ in spans)
+            padded = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            padded[:n_local] = t
+            buf = torch.empty((n_max * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(buf, padded, group=group)
+            full = torch.cat([buf[r * n_max:r * n_max + (b_ - a_)] for r, (a_, b_) in enumerate(spans)], dim=0)
         out[k] = full
     return out
 

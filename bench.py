@@ -175,8 +175,17 @@ def main():
         dom = max(fam, key=lambda k: fam[k]["ms"])
         d = fam[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if dom in pt["kernels"] and args.workload == "cfg3" and B == 32:
+                traffic, traffic_src = round(pt["kernels"][dom]), pt["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "launches_per_step": d["n"] // max(args.steps, 1), "avg_launch_ms": round(d["ms"] / d["n"], 4),
                     "flops_per_launch": d["flops"] / d["n"]}
         ms_step = elapsed / args.steps * 1e3

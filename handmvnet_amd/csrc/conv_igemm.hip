@@ -367,17 +367,15 @@ int conv_tile_bn(ConvTile t) {
     }
 }
 
-const char *conv_tile_name(ConvTile t, bool smallc) {
-    if (smallc) return "conv_igemm_f32<128x64,stem>";
-    switch (t) {
-        case TILE_128x32: return "conv_igemm_f32<128x32>";
-        case TILE_128x64: return "conv_igemm_f32<128x64>";
-        case TILE_128x128: return "conv_igemm_f32<128x128>";
-        case TILE_256x128: return "conv_igemm_f32<256x128>";
-        case TILE_128x256: return "conv_igemm_f32<128x256>";
-        case TILE_256x256: return "conv_igemm_f32<256x256>";
-        default: return "conv_igemm_f32<?>";
-    }
+// Family name = one rocprofv3 symbol: conv_igemm_f32<BM, BN, WGM, WGN, MODE, false>
+const char *conv_tile_name(ConvTile t, int mode) {
+    static const char *names[TILE_COUNT][2] = {
+        {"conv_igemm_f32<128x32,taps>", "conv_igemm_f32<128x32,1x1>"},   {"conv_igemm_f32<128x64,taps>", "conv_igemm_f32<128x64,1x1>"},
+        {"conv_igemm_f32<128x128,taps>", "conv_igemm_f32<128x128,1x1>"}, {"conv_igemm_f32<256x128,taps>", "conv_igemm_f32<256x128,1x1>"},
+        {"conv_igemm_f32<128x256,taps>", "conv_igemm_f32<128x256,1x1>"}, {"conv_igemm_f32<256x256,taps>", "conv_igemm_f32<256x256,1x1>"}};
+    if (mode == 2) return "conv_igemm_f32<128x64,stem>";
+    if (t < 0 || t >= TILE_COUNT) return "conv_igemm_f32<?>";
+    return names[t][mode == 1 ? 1 : 0];
 }
 
 ConvTile conv_pick_tile(int M, int Cout) {

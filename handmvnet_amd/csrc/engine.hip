@@ -638,7 +638,7 @@ struct Runner {
                 h->prof.push_back(r);
             }
             pr = &h->prof[h->prof_used++];
-            pr->name = conv_tile_name(tile, L.Cin < 32);
+            pr->name = conv_tile_name(tile, L.Cin < 32 ? 2 : ((L.R == 1 && L.S == 1 && pad_h == 0 && pad_w == 0) ? 1 : 0));
             pr->label = L.label;
             // algorithmic FLOPs: the real (un-padded) reduction length; the stem's 4th channel is padding
             const double kreal = (L.Cin == 4) ? (double)L.R * L.S * 3 : (double)L.K;

@@ -106,7 +106,7 @@ int hmv_read_stage(hmv_handle h, const char *stage, float *dst_device, size_t ca
  * clears them); hmv_profile_* read them back after the caller has synchronised the stream. */
 int hmv_set_profiling(hmv_handle h, int32_t enable);
 int hmv_profile_count(hmv_handle h);
-/* name: kernel symbol family ("conv_igemm_f32<128x128>" ...); label: layer ("layer3.2.conv2");
+/* name: kernel family = one device symbol ("conv_igemm_f32<256x256,1x1>" ...); label: layer ("layer3.2.conv2");
  * ms: duration; flops: algorithmic 2*M*N*K of that launch. */
 int hmv_profile_get(hmv_handle h, int32_t index, const char **name, const char **label, float *ms, double *flops);
 

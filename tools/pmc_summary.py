@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 PMC passes of `bench.py` into profiles/<tag>_pmc_summary.json and
+profiles/pmc_traffic.json (read by bench.py for roofline.traffic).
+
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES \
+              SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d DIR_sq -- python bench.py ...
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d DIR_fetch -- python bench.py ...
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d DIR_write -- python bench.py ...
+    python tools/pmc_summary.py TAG DIR_sq DIR_fetch DIR_write
+
+Corrections (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+reports exactly half of the bytes of wide (16 B/lane) coalesced reads, so it is doubled; WRITE_SIZE
+is exact for 16-byte-per-lane stores.  Every kernel here reads and writes 16 B per lane.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def family(name: str) -> str:
+    m = re.match(r"void hmv::conv_igemm_f32<(\d+), (\d+), \d+, \d+, (\d), (?:false|true)>", name)
+    if m:
+        return f"conv_igemm_f32<{m.group(1)}x{m.group(2)}," + {"0": "taps", "1": "1x1", "2": "stem"}[m.group(3)] + ">"
+    return re.sub(r"\(.*", "", name).replace("void ", "").replace("hmv::", "")
+
+
+def load(d):
+    return list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0])))
+
+
+def main():
+    tag, d_sq, d_fetch, d_write = sys.argv[1:5]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.Counter()
+    seen = set()
+    for r in load(d_sq):
+        f = family(r["Kernel_Name"])
+        agg[f][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            n[f] += 1
+            agg[f]["dur_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    sq = {}
+    for f, c in agg.items():
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0          # the counter sums the 8 XCDs
+        if not cyc or not c["SQ_WAVE_CYCLES"]:
+            continue
+        sq[f] = {"launches": n[f], "total_ms": round(c["dur_ns"] / 1e6, 3),
+                 "effective_clock_ghz": round(cyc / (c["dur_ns"] * 1e-9) / 1e9, 3),
+                 "mfma_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4),   # 1024 SIMDs
+                 "wave_parked_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                 "wave_issue_stall_frac": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                 "wave_active_frac": round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                 "lds_bank_conflict_per_wave_cycle": round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_WAVE_CYCLES"], 5)}
+    traffic = {}
+    for d, cn, corr in ((d_fetch, "FETCH_SIZE", 2.0), (d_write, "WRITE_SIZE", 1.0)):
+        a, k = collections.defaultdict(float), collections.Counter()
+        for r in load(d):
+            if r["Counter_Name"] == cn:
+                f = family(r["Kernel_Name"])
+                a[f] += float(r["Counter_Value"]) * 1024.0 * corr
+                k[f] += 1
+        for f in a:
+            traffic.setdefault(f, {})[cn.lower() + "_bytes_per_launch"] = a[f] / k[f]
+            traffic[f]["launches"] = k[f]
+    for f, t in traffic.items():
+        t["hbm_bytes_per_launch"] = t.get("fetch_size_bytes_per_launch", 0.0) + t.get("write_size_bytes_per_launch", 0.0)
+    out = {"tag": tag, "sq": dict(sorted(sq.items(), key=lambda kv: -kv[1]["total_ms"])), "traffic": traffic,
+           "corrections": "FETCH_SIZE x2 (gfx950 wide loads), KiB -> bytes; WRITE_SIZE exact"}
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
+    json.dump({"source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)",
+               "kernels": {f: t["hbm_bytes_per_launch"] for f, t in traffic.items()}},
+              open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    for f, v in list(out["sq"].items())[:6]:
+        print(f, v, {k: round(x / 1e6, 1) for k, x in traffic.get(f, {}).items() if k.endswith("launch")})
+
+
+if __name__ == "__main__":
+    main()

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhandmv.so")
+LIB_PATH = os.environ.get("HMV_LIB") or os.path.join(_HERE, "libhandmv.so")   # HMV_LIB: A/B-test another build
 
 # every symbol include/handmv.h declares
 SYMBOLS = ["hmv_create", "hmv_set_tensor", "hmv_finalize_weights", "hmv_workspace_bytes", "hmv_reserve", "hmv_forward",

@@ -44,7 +44,10 @@ namespace hmv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;
+constexpr int BK = 32;   // K granularity of the packed weights (Kpad % 32 == 0); kernels step by KB = 16 or 32
+#ifndef HMV_UB
+#define HMV_UB 4   // output rows (16-byte vectors) in flight per thread in the epilogue
+#endif
 
 // 256 bytes of zeros: out-of-range taps / rows DMA from here.
 static float *g_zero_page = nullptr;
@@ -64,15 +67,15 @@ enum { MODE_TAPS = 0,   // general R x S convolution, Cin % 32 == 0: the tap of 
 // Epilogue staging: per pass every wave stages AS of its 32-row accumulator blocks, so a pass holds
 // SR = WGM*AS*32 rows of BN+4 floats.  AS is the largest divisor of TM that fits the LDS budget
 // without growing the allocation (much) beyond the two tile buffers.
-constexpr int stage_blocks(int BM, int BN, int WGM) {
+constexpr int stage_blocks(int BM, int BN, int WGM, int KB) {
     const int TM = BM / WGM / 32;
     int as = TM;
-    while (as > 1 && (TM % as != 0 || WGM * as * 32 * (BN + 4) > 2 * (BM + BN) * BK + 1024)) --as;
+    while (as > 1 && (TM % as != 0 || WGM * as * 32 * (BN + 4) > 2 * (BM + BN) * KB + 1024)) --as;
     return as;
 }
-constexpr int lds_floats(int BM, int BN, int WGM) {
-    const int tile = 2 * (BM + BN) * BK;
-    const int stage = WGM * stage_blocks(BM, BN, WGM) * 32 * (BN + 4);
+constexpr int lds_floats(int BM, int BN, int WGM, int KB) {
+    const int tile = 2 * (BM + BN) * KB;
+    const int stage = WGM * stage_blocks(BM, BN, WGM, KB) * 32 * (BN + 4);
     return tile > stage ? tile : stage;
 }
 
@@ -84,19 +87,23 @@ constexpr int lds_floats(int BM, int BN, int WGM) {
 // place).  GENERIC = true adds the rarely used paths (sub-pixel output scatter, residual row remap,
 // GELU / LeakyReLU, row strides that are not multiples of 4); keeping them out of the hot
 // instantiation keeps its epilogue straight-line.
-template <int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC>
+template <int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParams p) {
     constexpr int NT = 64 * WGM * WGN;   // 4 or 8 waves
-    constexpr int RPS = NT / 8;          // tile rows filled per DMA pass (8 lanes per 128-byte row)
+    constexpr int LPR = KB / 4;          // lanes (16-byte chunks) per tile row: 8 (KB = 32) or 4 (KB = 16)
+    constexpr int RPW = 64 / LPR;        // rows filled by one wave-instruction (1 KiB): 8 or 16
+    constexpr int RPS = NT / LPR;        // tile rows filled per DMA pass
+    constexpr int NQ = KB / 8;           // MFMA groups per k-step (each: 4 MFMAs per 32x32 block pair)
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int AP = BM / RPS, BP = BN / RPS;
     constexpr int LDC = BN + 4;
-    constexpr int AS = stage_blocks(BM, BN, WGM), SR = WGM * AS * 32;
+    constexpr int AS = stage_blocks(BM, BN, WGM, KB), SR = WGM * AS * 32;
+    static_assert(KB == 16 || KB == 32, "k-step");
     static_assert(BM % RPS == 0 && BN % RPS == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
-    static_assert(TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM), "epilogue staging");
+    static_assert(TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM, KB), "epilogue staging");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sA = smem;                  // [2][BM][32]
-    float *sB = smem + 2 * BM * BK;    // [2][BN][32]
+    float *sA = smem;                  // [2][BM][KB]
+    float *sB = smem + 2 * BM * KB;    // [2][BN][KB]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,8 +124,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
 
     // ---- DMA roles: thread -> (row lrow of each RPS-row pass, physical chunk tid&7); it fetches the
     // LOGICAL chunk kqs so that the lane-linear LDS image ends up XOR-swizzled.
-    const int lrow = tid >> 3;
-    const int kqs = (tid & 7) ^ ((tid >> 4) & 7);
+    // swizzle: chunk' = chunk ^ f(row), f(row) = (row >> 1) & 7 for 128-byte rows, (row >> 2) & 3 for 64-byte rows
+    // (makes every 16-lane ds_read_b128 group hit 16 distinct 16-byte slots of the 256-byte bank row)
+    const int lrow = tid / LPR;
+    const int kqs = KB == 32 ? ((tid & 7) ^ ((tid >> 4) & 7)) : ((tid & 3) ^ ((tid >> 4) & 3));
     const float *zero = p.zero;
     const float *aptr[AP];
     int astep[AP], hi0[AP], wi0[AP];
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
         wi0[i] = wo * p.stride - p.pad_w;
         if (MODE == MODE_1X1) {
             aptr[i] = ok ? base + (hi0[i] * p.W + wi0[i]) * p.lda + 4 * kqs : zero;
-            astep[i] = ok ? BK : 0;
+            astep[i] = ok ? KB : 0;
         } else if (MODE == MODE_TAPS) {
             aptr[i] = base + (ok ? (hi0[i] * p.W + wi0[i]) * p.lda + 4 * kqs : 0);
             astep[i] = 0;
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     int cr = 0, cs = 0, cc = 0, cdelta = 0, ck = 0;   // load cursor (wave-uniform)
-    const int nk = p.Kpad / BK;
+    const int nk = p.Kpad / KB;
 
     // issue the DMA of the cursor tile into LDS buffer `buf`, then advance the cursor
 #define HMV_DMA(buf)                                                                                        \
@@ -182,33 +191,38 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
                 const bool ok_ = (unsigned)hi_ < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.W;            \
                 src_ = ok_ ? aptr[i] + (hi_ * p.W + wi_) * p.lda : zero;                                    \
             }                                                                                               \
-            HMV_GLDS16(src_, sA + ((buf) * BM + i * RPS + wave * 8) * BK);                                  \
+            HMV_GLDS16(src_, sA + ((buf) * BM + i * RPS + wave * RPW) * KB);                                \
         }                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < BP; ++i) {                                                    \
-            HMV_GLDS16(wptr[i], sB + ((buf) * BN + i * RPS + wave * 8) * BK);                               \
-            wptr[i] += BK;                                                                                  \
+            HMV_GLDS16(wptr[i], sB + ((buf) * BN + i * RPS + wave * RPW) * KB);                             \
+            wptr[i] += KB;                                                                                  \
         }                                                                                                   \
-        ck += BK;                                                                                           \
+        ck += KB;                                                                                           \
         if (MODE == MODE_TAPS) { /* K order: 32-channel chunk slowest, taps fastest (see ConvParams) */     \
-            cdelta += p.lda;                                                                                \
-            if (++cs == p.S) {                                                                              \
-                cs = 0;                                                                                     \
-                cdelta += (p.W - p.S) * p.lda;                                                              \
-                if (++cr == p.R) { cr = 0; cc += BK; cdelta = cc; }                                         \
+            if (KB == 16 && (ck & 16)) { /* second half of the same tap */                                  \
+                cdelta += 16;                                                                               \
+            } else {                                                                                        \
+                if (KB == 16) cdelta -= 16;                                                                 \
+                cdelta += p.lda;                                                                            \
+                if (++cs == p.S) {                                                                          \
+                    cs = 0;                                                                                 \
+                    cdelta += (p.W - p.S) * p.lda;                                                          \
+                    if (++cr == p.R) { cr = 0; cc += BK; cdelta = cc; }                                     \
+                }                                                                                           \
             }                                                                                               \
         }                                                                                                   \
     }
     // operand fetch: lane (row l31, k-half kh) reads logical chunk 2q+kh at its swizzled position
-    const int fsw = (l31 >> 1) & 7;
-    const float *arow = sA + (wm * WM + l31) * BK;
-    const float *brow = sB + (wn * WN + l31) * BK;
+    const int fsw = KB == 32 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
+    const float *arow = sA + (wm * WM + l31) * KB;
+    const float *brow = sB + (wn * WN + l31) * KB;
 #define HMV_FRAGS(FA, FB, buf, q)                                                                           \
     {                                                                                                       \
         const int ch_ = ((2 * (q) + kh) ^ fsw) * 4;                                                         \
         _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                      \
-            FA[a] = *reinterpret_cast<const f32x4 *>(arow + ((buf) * BM + a * 32) * BK + ch_);              \
+            FA[a] = *reinterpret_cast<const f32x4 *>(arow + ((buf) * BM + a * 32) * KB + ch_);              \
         _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                      \
-            FB[b] = *reinterpret_cast<const f32x4 *>(brow + ((buf) * BN + b * 32) * BK + ch_);              \
+            FB[b] = *reinterpret_cast<const f32x4 *>(brow + ((buf) * BN + b * 32) * KB + ch_);              \
     }
 #define HMV_MFMA(FA, FB)                                                                                    \
     {                                                                                                       \
@@ -233,21 +247,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        HMV_FRAGS(fa1, fb1, buf, 1);
-        HMV_MFMA(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        HMV_FRAGS(fa0, fb0, buf, 2);
-        HMV_MFMA(fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        HMV_FRAGS(fa1, fb1, buf, 3);
-        HMV_MFMA(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        // tile kt+1 (the only DMA in flight) must have landed; everyone is done reading `buf`
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 2 < nk) HMV_DMA(buf);
-        if (kt + 1 < nk) HMV_FRAGS(fa0, fb0, buf ^ 1, 0);
-        HMV_MFMA(fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {   // fragment sets alternate by the parity of q (NQ is even)
+            if (q + 1 < NQ) {
+                if (q & 1) { HMV_FRAGS(fa0, fb0, buf, q + 1); } else { HMV_FRAGS(fa1, fb1, buf, q + 1); }
+            } else {
+                // tile kt+1 (the only DMA in flight) must have landed; everyone is done reading `buf`
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (kt + 2 < nk) HMV_DMA(buf);
+                if (kt + 1 < nk) HMV_FRAGS(fa0, fb0, buf ^ 1, 0);
+            }
+            if (q & 1) { HMV_MFMA(fa1, fb1); } else { HMV_MFMA(fa0, fb0); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #undef HMV_DMA
 #undef HMV_FRAGS
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
             return ((size_t)n * (p.Ho * p.osy) + (ho * p.osy + p.ooy)) * (size_t)(p.Wo * p.osx) + (wo * p.osx + p.oox);
         };
         if (vec) {
-            constexpr int TPR = BN / 4, RPP = NT / TPR, NPASS = SR / RPP, UB = NPASS < 4 ? NPASS : 4;
+            constexpr int TPR = BN / 4, RPP = NT / TPR, NPASS = SR / RPP, UB = NPASS < HMV_UB ? NPASS : HMV_UB;
             static_assert(SR % RPP == 0 && NPASS % UB == 0, "staging pass shape");
             const int c4 = tid % TPR, r0 = tid / TPR;
             const int col = n0 + 4 * c4;
@@ -362,7 +374,7 @@ int conv_tile_bn(ConvTile t) {
     switch (t) {
         case TILE_128x32: return 32;
         case TILE_128x64: return 64;
-        case TILE_128x256: case TILE_256x256: return 256;
+        case TILE_128x256: case TILE_256x256: case TILE_128x256_K16: return 256;
         default: return 128;
     }
 }
@@ -372,18 +384,23 @@ const char *conv_tile_name(ConvTile t, int mode) {
     static const char *names[TILE_COUNT][2] = {
         {"conv_igemm_f32<128x32,taps>", "conv_igemm_f32<128x32,1x1>"},   {"conv_igemm_f32<128x64,taps>", "conv_igemm_f32<128x64,1x1>"},
         {"conv_igemm_f32<128x128,taps>", "conv_igemm_f32<128x128,1x1>"}, {"conv_igemm_f32<256x128,taps>", "conv_igemm_f32<256x128,1x1>"},
-        {"conv_igemm_f32<128x256,taps>", "conv_igemm_f32<128x256,1x1>"}, {"conv_igemm_f32<256x256,taps>", "conv_igemm_f32<256x256,1x1>"}};
+        {"conv_igemm_f32<128x256,taps>", "conv_igemm_f32<128x256,1x1>"}, {"conv_igemm_f32<256x256,taps>", "conv_igemm_f32<256x256,1x1>"},
+        {"conv_igemm_f32<128x128,k16,taps>", "conv_igemm_f32<128x128,k16,1x1>"},
+        {"conv_igemm_f32<128x256,k16,taps>", "conv_igemm_f32<128x256,k16,1x1>"}};
     if (mode == 2) return "conv_igemm_f32<128x64,stem>";
     if (t < 0 || t >= TILE_COUNT) return "conv_igemm_f32<?>";
     return names[t][mode == 1 ? 1 : 0];
 }
 
-ConvTile conv_pick_tile(int M, int Cout) {
+ConvTile conv_pick_tile(int M, int Cout, int K) {
     static int forced = -2;   // development knob: HMV_FORCE_TILE=<ConvTile> for layers with Cout > 64
     if (forced == -2) { const char *e = getenv("HMV_FORCE_TILE"); forced = e ? atoi(e) : -1; }
     if (Cout > 64 && forced >= 0 && forced < TILE_COUNT) return (ConvTile)forced;
     // Measured on MI355X (tools/conv_sweep.py): the matrix pipe is DVFS/power limited, so the tile with
     // the least L2->LDS traffic per FLOP wins as long as it still fills the 256 CUs for several rounds.
+    // tiny-K expanding convs (layer1/2 conv3 + residual) are epilogue/HBM-bound: 4 small blocks per CU
+    // overlap one block's residual read / store with the others' short main loops
+    if (Cout >= 256 && K <= 128 && M >= 65536) return TILE_128x128_K16;
     if (Cout > 128 && (long long)((M + 255) / 256) * ((Cout + 255) / 256) >= 512) return TILE_256x256;
     if (Cout > 64 && (long long)((M + 255) / 256) * ((Cout + 127) / 128) >= 512) return TILE_256x128;
     if (Cout > 64) return TILE_128x128;
@@ -391,11 +408,11 @@ ConvTile conv_pick_tile(int M, int Cout) {
     return TILE_128x32;
 }
 
-template <int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC>
+template <int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB = 32>
 static hipError_t launch_one(ConvParams p, hipStream_t s) {
     static bool configured = false;
-    const size_t lds = (size_t)lds_floats(BM, BN, WGM) * sizeof(float);
-    auto kern = conv_igemm_f32<BM, BN, WGM, WGN, MODE, GENERIC>;
+    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB) * sizeof(float);
+    auto kern = conv_igemm_f32<BM, BN, WGM, WGN, MODE, GENERIC, KB>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -413,9 +430,9 @@ static hipError_t launch_modes(const ConvParams &p, bool one, bool generic, hipS
     if (generic) return one ? launch_one<BM, BN, WGM, WGN, MODE_1X1, true>(p, s) : launch_one<BM, BN, WGM, WGN, MODE_TAPS, true>(p, s);
     return one ? launch_one<BM, BN, WGM, WGN, MODE_1X1, false>(p, s) : launch_one<BM, BN, WGM, WGN, MODE_TAPS, false>(p, s);
 }
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int KB = 32>
 static hipError_t launch_plain(const ConvParams &p, bool one, hipStream_t s) {
-    return one ? launch_one<BM, BN, WGM, WGN, MODE_1X1, false>(p, s) : launch_one<BM, BN, WGM, WGN, MODE_TAPS, false>(p, s);
+    return one ? launch_one<BM, BN, WGM, WGN, MODE_1X1, false, KB>(p, s) : launch_one<BM, BN, WGM, WGN, MODE_TAPS, false, KB>(p, s);
 }
 
 hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s) {
@@ -435,7 +452,8 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s) {
     }
     if (p.Cin % BK != 0) return hipErrorInvalidValue;
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
-    if (generic && (tile == TILE_256x128 || tile == TILE_128x256 || tile == TILE_256x256))
+    if (generic && (tile == TILE_256x128 || tile == TILE_128x256 || tile == TILE_256x256 || tile == TILE_128x128_K16 ||
+                    tile == TILE_128x256_K16))
         tile = TILE_128x128;   // the rarely used epilogue paths exist only for the 4-wave tiles
     switch (tile) {
         case TILE_128x32: return launch_modes<128, 32, 4, 1>(p, one, generic, s);
@@ -444,6 +462,8 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s) {
         case TILE_256x128: return launch_plain<256, 128, 4, 2>(p, one, s);
         case TILE_128x256: return launch_plain<128, 256, 2, 4>(p, one, s);
         case TILE_256x256: return launch_plain<256, 256, 2, 4>(p, one, s);
+        case TILE_128x128_K16: return launch_plain<128, 128, 2, 2, 16>(p, one, s);
+        case TILE_128x256_K16: return launch_plain<128, 256, 2, 2, 16>(p, one, s);
         default: return hipErrorInvalidValue;
     }
 }

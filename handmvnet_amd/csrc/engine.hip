@@ -560,7 +560,7 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
             (void)hipMemset(ddbg, 0, (size_t)nblk_dbg * 64);
             p.dbg = ddbg;
         }
-        const ConvTile t = tile < 0 ? conv_pick_tile(p.M, Cout) : (ConvTile)tile;
+        const ConvTile t = tile < 0 ? conv_pick_tile(p.M, Cout, K) : (ConvTile)tile;
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_conv(p, t, nullptr);
@@ -628,7 +628,7 @@ struct Runner {
         p.ldc = ldc; p.ldr = ldr; p.act = act;
         p.rg_out = rg_out; p.rg_in = rg_in;
         p.scatter = scatter; p.osy = scatter ? 2 : 1; p.osx = scatter ? 2 : 1; p.ooy = ooy; p.oox = oox;
-        const ConvTile tile = conv_pick_tile(p.M, p.Cout);
+        const ConvTile tile = conv_pick_tile(p.M, p.Cout, p.K);
         ProfRec *pr = nullptr;
         if (h->profiling) {
             if (h->prof_used == h->prof.size()) {
@@ -1007,7 +1007,7 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
         p.R = R; p.S = S; p.stride = stride; p.pad_h = pad; p.pad_w = pad;
         p.K = K; p.Kpad = Kpad; p.M = N * p.Ho * p.Wo; p.ldc = Cout; p.ldr = Cout;
         p.act = relu ? ACT_RELU : ACT_NONE; p.osy = p.osx = 1;
-        e = launch_conv(p, conv_pick_tile(p.M, Cout), static_cast<hipStream_t>(stream));
+        e = launch_conv(p, conv_pick_tile(p.M, Cout, K), static_cast<hipStream_t>(stream));
         if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
     }
     if (dw) (void)hipFree(dw);

@@ -118,8 +118,8 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
                   int32_t stride, int32_t pad, const float *residual, int32_t relu, float *out, void *stream);
 
 /* Diagnostic micro-benchmark: average milliseconds of `iters` launches of one NHWC conv shape on
- * pseudo-random data.  tile: -1 = the engine's own choice, else 0..5 = 128x32, 128x64, 128x128, 256x128,
- * 128x256, 256x256 (BM x BN).  HMV_BENCH_CLOCK=1 adds in-kernel clock stamps (stderr). */
+ * pseudo-random data.  tile: -1 = the engine's own choice, else 0..7 = 128x32, 128x64, 128x128, 256x128,
+ * 128x256, 256x256, 128x128 (k-step 16), 128x256 (k-step 16) (BM x BN).  HMV_BENCH_CLOCK=1 adds in-kernel clock stamps (stderr). */
 int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t R, int32_t S,
                    int32_t stride, int32_t pad, int32_t with_residual, int32_t tile, int32_t iters, float *avg_ms);
 

@@ -293,91 +293,136 @@ hipError_t launch_layernorm(const float *x, int ldx, int rows, int d, const floa
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------ attention, one workgroup per (sample, head)
-// layers.py:216-221: dots = q k^T * 128^-0.5 ; softmax ; attn v.  T <= 256 keys: the whole K of a head
-// sits in LDS ([Tk][129] floats, conflict-free for "lane = key" reads); each wave owns query rows
-// i = wave, wave+4, ...: lane = key for the scores, lane = channel pair for P.V (V streamed from L2).
-constexpr int ATT_KPL = 4;  // keys per lane -> Tk <= 256
-__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ qkv, int T, int Tq, int koff, int Tk,
-                                                        float *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *sK = sm;                 // [Tk][129]
-    float *sQ = sm + Tk * 129;      // [4 waves][128]
-    float *sP = sQ + 4 * 128;       // [4 waves][Tk]
+// ------------------------------------------------------------------ attention on the fp32 matrix cores
+// layers.py:216-221: dots = q k^T * 128^-0.5 ; softmax over keys ; out = attn v      (8 heads x 128)
+// One workgroup (4 waves) per (sample, head).  Flash-style: keys are walked in chunks of 32; the K and V
+// chunks are staged through LDS once per workgroup and shared by the 4 waves; each wave owns 32-row query
+// blocks (q-block w, w+4, ... in successive passes) with Q held in registers as the MFMA A operand.
+//   S  = Q_blk K_chunk^T   64 x v_mfma_f32_32x32x2_f32 (k = 128)          -> 16 accumulator registers
+//   online softmax: running row max via 5 wave shuffles per accumulator register, running row sum kept
+//   lane-private (one column per lane) and reduced across lanes once at the end
+//   P (C layout, key on the lane) -> per-wave LDS scratch -> A layout (query row on the lane)
+//   O += P V_chunk          64 x MFMA (4 channel blocks x 16 k-pairs)     -> 64 accumulator registers
+// The k order inside every 8-wide group is permuted identically for both operands (16-byte reads).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int ATT_LDK = 132;   // K chunk row stride (floats): conflict-free ds_read_b128 of the B operand
+constexpr int ATT_LDP = 36;    // P scratch row stride
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__restrict__ qkv, int T, int Tq, int koff, int Tk,
+                                                             float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float sK[32 * ATT_LDK];
+    __shared__ __attribute__((aligned(16))) float sV[32 * 128];
+    __shared__ __attribute__((aligned(16))) float sP[4][32 * ATT_LDP];
     const int b = blockIdx.x >> 3, h = blockIdx.x & 7;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
     const size_t ld = 3 * 1024;
     const float *base = qkv + (size_t)b * T * ld;
-    for (int i = tid; i < Tk * 32; i += 256) {
-        const int j = i >> 5, c4 = i & 31;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (size_t)(koff + j) * ld + 1024 + h * 128 + 4 * c4);
-        float *dst = sK + j * 129 + 4 * c4;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-    }
-    __syncthreads();
+    const float *qb = base + h * 128, *kb = base + (size_t)koff * ld + 1024 + h * 128, *vb = base + (size_t)koff * ld + 2048 + h * 128;
+    const int nqb = (Tq + 31) >> 5, nkc = (Tk + 31) >> 5;
     const float scale = 0.08838834764831845f;  // 128 ** -0.5
-    float *q = sQ + wave * 128, *pr = sP + wave * Tk;
-    for (int i = wave; i < Tq; i += 4) {
-        const float *qrow = base + (size_t)i * ld + h * 128;
-        q[lane] = qrow[lane];
-        q[lane + 64] = qrow[lane + 64];
-        __builtin_amdgcn_wave_barrier();
-        float sc[ATT_KPL], mx = -INFINITY;
+    float *pw = sP[wave];
+
+    for (int pass = 0; pass * 4 < nqb; ++pass) {
+        const int qblk = pass * 4 + wave;
+        const bool active = qblk < nqb;              // wave-uniform
+        const int qrow = qblk * 32 + l31;
+        // Q block as the A operand: lane (row l31, k-half kh) holds Q[row][8u + 4kh + e]
+        f32x4 qa[16];
 #pragma unroll
-        for (int u = 0; u < ATT_KPL; ++u) {
-            const int j = lane + 64 * u;
-            float a = 0.f;
-            if (j < Tk) {
-                const float *kr = sK + j * 129;
-#pragma unroll 8
-                for (int c = 0; c < 128; ++c) a += q[c] * kr[c];
-                a *= scale;
-                mx = fmaxf(mx, a);
+        for (int u = 0; u < 16; ++u) {
+            qa[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (active && qrow < Tq) qa[u] = *reinterpret_cast<const f32x4 *>(qb + (size_t)qrow * ld + 8 * u + 4 * kh);
+        }
+        f32x16 o[4];
+        float m_run[16], l_run[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[c][e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { m_run[e] = -INFINITY; l_run[e] = 0.f; }
+
+        for (int kc = 0; kc < nkc; ++kc) {
+            __syncthreads();   // previous chunk fully consumed
+            // stage K and V chunk (32 keys x 128): 1024 + 1024 16-byte vectors, 8 per thread; keys >= Tk are zeros
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 256 + tid, j = idx >> 5, c4 = idx & 31, key = kc * 32 + j;
+                f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+                if (key < Tk) {
+                    kv = *reinterpret_cast<const f32x4 *>(kb + (size_t)key * ld + 4 * c4);
+                    vv = *reinterpret_cast<const f32x4 *>(vb + (size_t)key * ld + 4 * c4);
+                }
+                *reinterpret_cast<f32x4 *>(&sK[j * ATT_LDK + 4 * c4]) = kv;
+                *reinterpret_cast<f32x4 *>(&sV[j * 128 + 4 * c4]) = vv;
             }
-            sc[u] = a;
-        }
-        mx = wave_max(mx);
-        float sum = 0.f;
+            __syncthreads();
+            if (!active) continue;
+            // ---- S = Q K^T (32 x 32), key on the lane
+            f32x16 sacc;
 #pragma unroll
-        for (int u = 0; u < ATT_KPL; ++u) {
-            const int j = lane + 64 * u;
-            if (j < Tk) {
-                sc[u] = expf(sc[u] - mx);
-                sum += sc[u];
+            for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const f32x4 kf = *reinterpret_cast<const f32x4 *>(&sK[l31 * ATT_LDK + 8 * u + 4 * kh]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[u][e], kf[e], sacc, 0, 0, 0);
+            }
+            // ---- online softmax.  Register e holds row (e&3) + 8*(e>>2) + 4*kh, column = this lane's key
+            const bool kvalid = kc * 32 + l31 < Tk;
+            float alpha[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float sv = kvalid ? sacc[e] * scale : -INFINITY;
+                float mx = sv;
+#pragma unroll
+                for (int ofs = 16; ofs > 0; ofs >>= 1) mx = fmaxf(mx, __shfl_xor(mx, ofs, 64));   // stays inside the 32-lane half
+                const float m_new = fmaxf(m_run[e], mx);                                        // finite: chunk has >= 1 valid key
+                alpha[e] = expf(m_run[e] - m_new);                                                 // exp(-inf) = 0 on the first chunk
+                const float pe = kvalid ? expf(sv - m_new) : 0.f;
+                l_run[e] = l_run[e] * alpha[e] + pe;
+                m_run[e] = m_new;
+                pw[((e & 3) + 8 * (e >> 2) + 4 * kh) * ATT_LDP + l31] = pe;                     // P[row][key]
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[c][e] *= alpha[e];
+            __builtin_amdgcn_wave_barrier();
+            // ---- O += P V: A = P (query row on the lane), B = V chunk (channel on the lane)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 pf = *reinterpret_cast<const f32x4 *>(&pw[l31 * ATT_LDP + 8 * u + 4 * kh]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float *vrow = &sV[(8 * u + 4 * kh + e) * 128 + l31];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[e], vrow[32 * c], o[c], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float l = l_run[e];
+#pragma unroll
+                for (int ofs = 16; ofs > 0; ofs >>= 1) l += __shfl_xor(l, ofs, 64);
+                const float inv = 1.f / l;
+                const int row = qblk * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (row < Tq) {
+                    float *orow = out + ((size_t)b * Tq + row) * 1024 + h * 128 + l31;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) orow[32 * c] = o[c][e] * inv;
+                }
             }
         }
-        sum = wave_sum(sum);
-        const float inv = 1.f / sum;
-#pragma unroll
-        for (int u = 0; u < ATT_KPL; ++u) {
-            const int j = lane + 64 * u;
-            if (j < Tk) pr[j] = sc[u] * inv;
-        }
-        __builtin_amdgcn_wave_barrier();
-        float o0 = 0.f, o1 = 0.f;
-        const float *vbase = base + (size_t)koff * ld + 2048 + h * 128 + 2 * lane;
-        for (int j = 0; j < Tk; ++j) {
-            const float2 vv = *reinterpret_cast<const float2 *>(vbase + (size_t)j * ld);
-            const float pj = pr[j];
-            o0 += pj * vv.x;
-            o1 += pj * vv.y;
-        }
-        float *orow = out + ((size_t)b * Tq + i) * 1024 + h * 128 + 2 * lane;
-        *reinterpret_cast<float2 *>(orow) = make_float2(o0, o1);
-        __builtin_amdgcn_wave_barrier();
     }
 }
 hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s) {
-    if (Tk > 64 * ATT_KPL) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)Tk * 129 + 4 * 128 + 4 * (size_t)Tk) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
-    hipLaunchKernelGGL(attention_kernel, dim3(B * 8), dim3(256), lds, s, qkv, T, Tq, koff, Tk, out);
+    if (Tk <= 0 || Tq <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3(B * 8), dim3(256), 0, s, qkv, T, Tq, koff, Tk, out);
     return hipGetLastError();
 }
 

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
 int conv_tile_bn(ConvTile t) {
     switch (t) {
         case TILE_128x32: return 32;
-        case TILE_128x64: return 64;
+        case TILE_128x64: case TILE_64x64: return 64;
         case TILE_128x256: case TILE_256x256: case TILE_128x256_K16: return 256;
         default: return 128;
     }
@@ -386,7 +386,9 @@ const char *conv_tile_name(ConvTile t, int mode) {
         {"conv_igemm_f32<128x128,taps>", "conv_igemm_f32<128x128,1x1>"}, {"conv_igemm_f32<256x128,taps>", "conv_igemm_f32<256x128,1x1>"},
         {"conv_igemm_f32<128x256,taps>", "conv_igemm_f32<128x256,1x1>"}, {"conv_igemm_f32<256x256,taps>", "conv_igemm_f32<256x256,1x1>"},
         {"conv_igemm_f32<128x128,k16,taps>", "conv_igemm_f32<128x128,k16,1x1>"},
-        {"conv_igemm_f32<128x256,k16,taps>", "conv_igemm_f32<128x256,k16,1x1>"}};
+        {"conv_igemm_f32<128x256,k16,taps>", "conv_igemm_f32<128x256,k16,1x1>"},
+        {"conv_igemm_f32<256x128,k16,taps>", "conv_igemm_f32<256x128,k16,1x1>"},
+        {"conv_igemm_f32<64x64,taps>", "conv_igemm_f32<64x64,1x1>"}};
     if (mode == 2) return "conv_igemm_f32<128x64,stem>";
     if (t < 0 || t >= TILE_COUNT) return "conv_igemm_f32<?>";
     return names[t][mode == 1 ? 1 : 0];
@@ -403,6 +405,9 @@ ConvTile conv_pick_tile(int M, int Cout, int K) {
     if (Cout >= 256 && K <= 128 && M >= 65536) return TILE_128x128_K16;
     if (Cout > 128 && (long long)((M + 255) / 256) * ((Cout + 255) / 256) >= 512) return TILE_256x256;
     if (Cout > 64 && (long long)((M + 255) / 256) * ((Cout + 127) / 128) >= 512) return TILE_256x128;
+    // small problems (few frames, or the token GEMMs of the fusion transformer): 64x64 tiles give 4x the
+    // workgroups and 4x shorter k-steps, which is what matters when the 128-wide tiling cannot fill 256 CUs
+    if (Cout > 32 && (long long)((M + 127) / 128) * ((Cout + 127) / 128) < 256) return TILE_64x64;
     if (Cout > 64) return TILE_128x128;
     if (Cout > 32) return TILE_128x64;
     return TILE_128x32;
@@ -453,7 +458,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s) {
     if (p.Cin % BK != 0) return hipErrorInvalidValue;
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
     if (generic && (tile == TILE_256x128 || tile == TILE_128x256 || tile == TILE_256x256 || tile == TILE_128x128_K16 ||
-                    tile == TILE_128x256_K16))
+                    tile == TILE_128x256_K16 || tile == TILE_256x128_K16))
         tile = TILE_128x128;   // the rarely used epilogue paths exist only for the 4-wave tiles
     switch (tile) {
         case TILE_128x32: return launch_modes<128, 32, 4, 1>(p, one, generic, s);
@@ -464,6 +469,8 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s) {
         case TILE_256x256: return launch_plain<256, 256, 2, 4>(p, one, s);
         case TILE_128x128_K16: return launch_plain<128, 128, 2, 2, 16>(p, one, s);
         case TILE_128x256_K16: return launch_plain<128, 256, 2, 2, 16>(p, one, s);
+        case TILE_256x128_K16: return launch_plain<256, 128, 2, 2, 16>(p, one, s);
+        case TILE_64x64: return launch_modes<64, 64, 2, 2>(p, one, generic, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -307,7 +307,7 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     if (!cfg || !out) return bad("null argument");
     if (cfg->struct_size != (int32_t)sizeof(hmv_config)) return bad("hmv_config.struct_size mismatch (ABI)");
     if (cfg->backbone < HMV_RESNET18 || cfg->backbone > HMV_RESNET50_PAPER) return bad("Supports only 18, 34, 50_paper");
-    if (cfg->num_views < 1 || cfg->num_views > 12) return bad("num_views must be in [1, 12]");
+    if (cfg->num_views < 1 || cfg->num_views > 48) return bad("num_views must be in [1, 48]");
     if (cfg->fusion_layers < 1 || cfg->fusion_layers % 2 != 1) return bad("num_layers must be an odd number");
     if (cfg->dtype != HMV_F32) { g_create_err = "only HMV_F32 is built"; return HMV_ERR_UNSUPPORTED; }
     if (cfg->height < 32 || cfg->width < 32 || cfg->height % 32 || cfg->width % 32)

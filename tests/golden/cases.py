@@ -24,6 +24,10 @@ CASES = {
                              iseed=17, freeze_bn=True, fusion_layers=3),
     # ResNet-34, single sampled level
     "r34_onelevel": dict(bt="34", ch=[256], V=2, B=1, size=64, pos=ALL_POS, gcn=True, wseed=8, iseed=18),
+    # a single view: the cross-attention block has ZERO keys (x[:, 21:] is empty), fusion.py:19 / layers.py:207
+    "r18_single_view": dict(bt="18", ch=[256, 128, 64], V=1, B=3, size=64, pos=ALL_POS, gcn=True, wseed=10, iseed=20),
+    # more views than any release config (13 x 21 = 273 tokens)
+    "r18_13views": dict(bt="18", ch=[256, 128, 64], V=13, B=1, size=64, pos=ALL_POS, gcn=False, wseed=11, iseed=21),
     # non-power-of-two input, config constants that differ from the tensor shapes (handmvnet.py:252 quirk)
     "r50_odd_96": dict(bt="50_paper", ch=[1024], V=5, B=1, size=96, pos=ALL_POS, gcn=True, wseed=9, iseed=19,
                        image_size=200, heatmap_size=32),

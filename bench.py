@@ -35,6 +35,7 @@ from handmvnet_amd.spec import config_from_params, conv_flops_per_image  # noqa:
 from handmvnet_amd.synth import synth_inputs, synth_state_dict  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 WORKLOADS = {
     # name: (backbone_type, channels, V, B per GPU, size)
@@ -101,6 +102,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"], help="f16 = BASELINE configs[4] (fp16 conv stack)")
     ap.add_argument("--per-layer", default="", help="write per-layer launch timings (JSON) to this file")
     args = ap.parse_args()
 
@@ -110,11 +112,18 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    dev = torch.device(f"cuda:{local_rank}")
+    # rehearsal switches for a one-GPU box: HMV_BENCH_SAME_DEVICE=1 maps every rank to cuda:0 and
+    # HMV_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU); never set by the driver
+    same_dev = os.environ.get("HMV_BENCH_SAME_DEVICE") == "1"
+    backend = os.environ.get("HMV_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda:0" if same_dev else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     bt, ch, V, B, size = WORKLOADS[args.workload]
     if args.batch:
@@ -126,6 +135,8 @@ def main():
     model.load_state_dict(sd, strict=True)
     model.to(dev).eval()
     model.freeze()
+    if args.dtype == "f16":
+        model.half()
 
     # synthetic frames of this rank's shard, resident in HBM before the timed region
     x, bbox, intr = synth_inputs(cfg, B, 1000 + rank, size)
@@ -175,16 +186,17 @@ def main():
         dom = max(fam, key=lambda k: fam[k]["ms"])
         d = fam[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        peak = PEAK_F16_MFMA_TFLOPS if "f16" in dom else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_src = None, None
         try:   # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pt = json.load(f)
-            if dom in pt["kernels"] and args.workload == "cfg3" and B == 32:
+            if dom in pt["kernels"] and args.workload == "cfg3" and B == 32 and args.dtype == "f32":
                 traffic, traffic_src = round(pt["kernels"][dom]), pt["source"]
         except (OSError, ValueError, KeyError):
             pass
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "launches_per_step": d["n"] // max(args.steps, 1), "avg_launch_ms": round(d["ms"] / d["n"], 4),
                     "flops_per_launch": d["flops"] / d["n"]}
@@ -194,7 +206,7 @@ def main():
             "metric": "samples/sec (BxV frames) eval_fps.py, 8-view 256x256; 21-kpt L2 vs reference",
             "value": round(args.steps * B * V * world / elapsed, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{2 if args.workload == 'cfg3' else 1}]: B={B}/GPU x V={V} x {size}x{size}, "
                                    f"resnet{bt} backbone, d={cfg.feat_dim}, cross_attn x{cfg.fusion_layers}, GCN decoder",
                        "global_batch": B * world, "views": V, "frame": size, "parallelism": f"sample-shard x{world}"},

@@ -43,6 +43,8 @@ namespace hmv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;   // K granularity of the packed weights (Kpad % 32 == 0); kernels step by KB = 16 or 32
 #ifndef HMV_UB
@@ -67,6 +69,7 @@ enum { MODE_TAPS = 0,   // general R x S convolution, Cin % 32 == 0: the tap of 
 // Epilogue staging: per pass every wave stages AS of its 32-row accumulator blocks, so a pass holds
 // SR = WGM*AS*32 rows of BN+4 floats.  AS is the largest divisor of TM that fits the LDS budget
 // without growing the allocation (much) beyond the two tile buffers.
+// (KB is given in 4-byte units here: the kernels pass KB * sizeof(T) / 4)
 constexpr int stage_blocks(int BM, int BN, int WGM, int KB) {
     const int TM = BM / WGM / 32;
     int as = TM;
@@ -87,23 +90,31 @@ constexpr int lds_floats(int BM, int BN, int WGM, int KB) {
 // place).  GENERIC = true adds the rarely used paths (sub-pixel output scatter, residual row remap,
 // GELU / LeakyReLU, row strides that are not multiples of 4); keeping them out of the hot
 // instantiation keeps its epilogue straight-line.
-template <int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParams p) {
+// T = float: v_mfma_f32_32x32x2_f32, 4 elements per 16-byte chunk, KB = 32 (or 16) elements per k-step.
+// T = _Float16 (BASELINE configs[4]): v_mfma_f32_32x32x16_f16 with fp32 accumulation, 8 elements per chunk,
+// KB = 64: the LDS image, the DMA pattern and the swizzle are byte-identical to the fp32 kernel; one
+// 16-byte chunk is exactly one MFMA operand (k = 8*kh + j), so a q-group is ONE MFMA per block pair.
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p) {
+    constexpr bool F16 = sizeof(T) == 2;
+    constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
+    constexpr int CH = F16 ? 64 : 32;    // channel-chunk width of the packed K order
+    constexpr int KB4 = KB * (int)sizeof(T) / 4;   // k-step in 4-byte units (row bytes / 4)
     constexpr int NT = 64 * WGM * WGN;   // 4 or 8 waves
-    constexpr int LPR = KB / 4;          // lanes (16-byte chunks) per tile row: 8 (KB = 32) or 4 (KB = 16)
+    constexpr int LPR = KB / EPC;        // lanes (16-byte chunks) per tile row: 8 (128-byte rows) or 4 (64-byte rows)
     constexpr int RPW = 64 / LPR;        // rows filled by one wave-instruction (1 KiB): 8 or 16
     constexpr int RPS = NT / LPR;        // tile rows filled per DMA pass
-    constexpr int NQ = KB / 8;           // MFMA groups per k-step (each: 4 MFMAs per 32x32 block pair)
+    constexpr int NQ = LPR / 2;          // MFMA groups per k-step (two chunks, k-halves 0/1, per group)
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int AP = BM / RPS, BP = BN / RPS;
     constexpr int LDC = BN + 4;
-    constexpr int AS = stage_blocks(BM, BN, WGM, KB), SR = WGM * AS * 32;
-    static_assert(KB == 16 || KB == 32, "k-step");
+    constexpr int AS = stage_blocks(BM, BN, WGM, KB4), SR = WGM * AS * 32;
+    static_assert(KB == CH || KB == CH / 2, "k-step");
     static_assert(BM % RPS == 0 && BN % RPS == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
-    static_assert(TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM, KB), "epilogue staging");
+    static_assert(TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM, KB4), "epilogue staging");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sA = smem;                  // [2][BM][KB]
-    float *sB = smem + 2 * BM * KB;    // [2][BN][KB]
+    T *sA = reinterpret_cast<T *>(smem);   // [2][BM][KB]
+    T *sB = sA + 2 * BM * KB;              // [2][BN][KB]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,9 +138,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
     // swizzle: chunk' = chunk ^ f(row), f(row) = (row >> 1) & 7 for 128-byte rows, (row >> 2) & 3 for 64-byte rows
     // (makes every 16-lane ds_read_b128 group hit 16 distinct 16-byte slots of the 256-byte bank row)
     const int lrow = tid / LPR;
-    const int kqs = KB == 32 ? ((tid & 7) ^ ((tid >> 4) & 7)) : ((tid & 3) ^ ((tid >> 4) & 3));
-    const float *zero = p.zero;
-    const float *aptr[AP];
+    const int kqs = LPR == 8 ? ((tid & 7) ^ ((tid >> 4) & 7)) : ((tid & 3) ^ ((tid >> 4) & 3));
+    const T *zero = reinterpret_cast<const T *>(p.zero);
+    const T *aptr[AP];
     int astep[AP], hi0[AP], wi0[AP];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -139,23 +150,24 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
         const int mm = ok ? m : 0;
         const int n = mm / HoWo, rem = mm - n * HoWo;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        const float *base = p.in + (size_t)n * p.H * p.W * p.lda;
+        const T *base = reinterpret_cast<const T *>(p.in) + (size_t)n * p.H * p.W * p.lda;
         hi0[i] = ok ? ho * p.stride - p.pad_h : -(1 << 28);   // out-of-range rows fail every bounds test
         wi0[i] = wo * p.stride - p.pad_w;
         if (MODE == MODE_1X1) {
-            aptr[i] = ok ? base + (hi0[i] * p.W + wi0[i]) * p.lda + 4 * kqs : zero;
+            aptr[i] = ok ? base + (hi0[i] * p.W + wi0[i]) * p.lda + EPC * kqs : zero;
             astep[i] = ok ? KB : 0;
         } else if (MODE == MODE_TAPS) {
-            aptr[i] = base + (ok ? (hi0[i] * p.W + wi0[i]) * p.lda + 4 * kqs : 0);
+            aptr[i] = base + (ok ? (hi0[i] * p.W + wi0[i]) * p.lda + EPC * kqs : 0);
             astep[i] = 0;
         } else {
             aptr[i] = base;
             astep[i] = 0;
         }
     }
-    const float *wptr[BP];
+    const T *wptr[BP];
 #pragma unroll
-    for (int i = 0; i < BP; ++i) wptr[i] = p.wgt + (size_t)(nt * BN + i * RPS + lrow) * p.ldw + 4 * kqs;
+    for (int i = 0; i < BP; ++i)
+        wptr[i] = reinterpret_cast<const T *>(p.wgt) + (size_t)(nt * BN + i * RPS + lrow) * p.ldw + EPC * kqs;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -173,13 +185,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
     {                                                                                                       \
         int sr_ = 0, ss_ = 0;                                                                               \
         if (MODE == MODE_SMALLC) { /* lane-private tap of this 16-byte vector */                            \
-            const int tap_ = (ck >> 2) + kqs;                                                               \
+            const int tap_ = ck / EPC + kqs;                                                                \
             sr_ = tap_ / p.S;                                                                               \
             ss_ = tap_ - sr_ * p.S;                                                                         \
             if (tap_ >= p.R * p.S) sr_ = 1 << 28;                                                           \
         }                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                    \
-            const float *src_;                                                                              \
+            const T *src_;                                                                                  \
             if (MODE == MODE_1X1) {                                                                         \
                 src_ = aptr[i];                                                                             \
                 aptr[i] += astep[i];                                                                        \
@@ -199,26 +211,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
         }                                                                                                   \
         ck += KB;                                                                                           \
         if (MODE == MODE_TAPS) { /* K order: 32-channel chunk slowest, taps fastest (see ConvParams) */     \
-            if (KB == 16 && (ck & 16)) { /* second half of the same tap */                                  \
-                cdelta += 16;                                                                               \
+            if (KB == CH / 2 && (ck & (CH / 2))) { /* second half of the same tap */                        \
+                cdelta += CH / 2;                                                                           \
             } else {                                                                                        \
-                if (KB == 16) cdelta -= 16;                                                                 \
+                if (KB == CH / 2) cdelta -= CH / 2;                                                         \
                 cdelta += p.lda;                                                                            \
                 if (++cs == p.S) {                                                                          \
                     cs = 0;                                                                                 \
                     cdelta += (p.W - p.S) * p.lda;                                                          \
-                    if (++cr == p.R) { cr = 0; cc += BK; cdelta = cc; }                                     \
+                    if (++cr == p.R) { cr = 0; cc += CH; cdelta = cc; }                                     \
                 }                                                                                           \
             }                                                                                               \
         }                                                                                                   \
     }
     // operand fetch: lane (row l31, k-half kh) reads logical chunk 2q+kh at its swizzled position
-    const int fsw = KB == 32 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
-    const float *arow = sA + (wm * WM + l31) * KB;
-    const float *brow = sB + (wn * WN + l31) * KB;
+    const int fsw = LPR == 8 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
+    const T *arow = sA + (wm * WM + l31) * KB;
+    const T *brow = sB + (wn * WN + l31) * KB;
 #define HMV_FRAGS(FA, FB, buf, q)                                                                           \
     {                                                                                                       \
-        const int ch_ = ((2 * (q) + kh) ^ fsw) * 4;                                                         \
+        const int ch_ = ((2 * (q) + kh) ^ fsw) * EPC;                                                       \
         _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                      \
             FA[a] = *reinterpret_cast<const f32x4 *>(arow + ((buf) * BM + a * 32) * KB + ch_);              \
         _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                      \
@@ -226,10 +238,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
     }
 #define HMV_MFMA(FA, FB)                                                                                    \
     {                                                                                                       \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                       \
+        if constexpr (F16) {                                                                                \
             _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                  \
                 _Pragma("unroll") for (int b = 0; b < TN; ++b)                                              \
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a][e], FB[b][e], acc[a][b], 0, 0, 0); \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, FA[a]),    \
+                                                                       __builtin_bit_cast(f16x8, FB[b]), acc[a][b], 0, 0, 0); \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                   \
+                _Pragma("unroll") for (int a = 0; a < TM; ++a)                                              \
+                    _Pragma("unroll") for (int b = 0; b < TN; ++b)                                          \
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a][e], FB[b][e], acc[a][b], 0, 0, 0); \
+        }                                                                                                   \
     }
 
     f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
@@ -320,8 +339,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
                             if (p.scatter) orow[u] = out_row(m);
                             if (p.rg_out) rrow = (size_t)(m / p.rg_out) * p.rg_in + (m % p.rg_out);
                         }
-                        const float *rp = (has_res && okr[u]) ? p.res + rrow * p.ldr + col : zero;
-                        rv[u] = *reinterpret_cast<const f32x4 *>(rp);
+                        if (p.res_f16) {   // fp16 residual: 4 halfs = 8 bytes
+                            const _Float16 *rp = (has_res && okr[u]) ? reinterpret_cast<const _Float16 *>(p.res) + rrow * p.ldr + col
+                                                                      : reinterpret_cast<const _Float16 *>(p.zero);
+                            const f16x4 hv = *reinterpret_cast<const f16x4 *>(rp);
+                            rv[u] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                        } else {
+                            const float *rp = (has_res && okr[u]) ? reinterpret_cast<const float *>(p.res) + rrow * p.ldr + col : p.zero;
+                            rv[u] = *reinterpret_cast<const f32x4 *>(rp);
+                        }
                         v[u] = *reinterpret_cast<const f32x4 *>(&sC[sr * LDC + 4 * c4]);
                     }
 #pragma unroll
@@ -338,7 +364,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], lo);
-                        if (okr[u]) *reinterpret_cast<f32x4 *>(p.out + orow[u] * p.ldc + col) = t;
+                        if (okr[u]) {
+                            if (p.out_f16)
+                                *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + orow[u] * p.ldc + col) =
+                                    f16x4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+                            else
+                                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out) + orow[u] * p.ldc + col) = t;
+                        }
                     }
                 }
             }
@@ -350,11 +382,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32(const ConvParam
                 const size_t orow = p.scatter ? out_row(m) : (size_t)m;
                 const size_t rrow = p.rg_out ? (size_t)(m / p.rg_out) * p.rg_in + (m % p.rg_out) : (size_t)m;
                 float v = sC[sr * LDC + c] + p.bias[col];
-                if (p.res) v += p.res[rrow * p.ldr + col];
+                if (p.res) v += p.res_f16 ? (float)reinterpret_cast<const _Float16 *>(p.res)[rrow * p.ldr + col]
+                                          : reinterpret_cast<const float *>(p.res)[rrow * p.ldr + col];
                 if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
                 else if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
                 else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-                p.out[orow * p.ldc + col] = v;
+                if (p.out_f16) reinterpret_cast<_Float16 *>(p.out)[orow * p.ldc + col] = (_Float16)v;
+                else reinterpret_cast<float *>(p.out)[orow * p.ldc + col] = v;
             }
         }
     }
@@ -379,7 +413,18 @@ int conv_tile_bn(ConvTile t) {
     }
 }
 
-// Family name = one rocprofv3 symbol: conv_igemm_f32<BM, BN, WGM, WGN, MODE, false>
+// Family name = one rocprofv3 symbol: conv_igemm<T, BM, BN, WGM, WGN, MODE, false, KB>
+const char *conv_tile_name_f16(ConvTile t, int mode) {
+    static const char *names[TILE_COUNT][2] = {
+        {"conv_igemm_f16<128x32,taps>", "conv_igemm_f16<128x32,1x1>"},   {"conv_igemm_f16<128x64,taps>", "conv_igemm_f16<128x64,1x1>"},
+        {"conv_igemm_f16<128x128,taps>", "conv_igemm_f16<128x128,1x1>"}, {"conv_igemm_f16<256x128,taps>", "conv_igemm_f16<256x128,1x1>"},
+        {"conv_igemm_f16<128x256,taps>", "conv_igemm_f16<128x256,1x1>"}, {"conv_igemm_f16<256x256,taps>", "conv_igemm_f16<256x256,1x1>"},
+        {"conv_igemm_f16<128x128,taps>", "conv_igemm_f16<128x128,1x1>"}, {"conv_igemm_f16<128x256,taps>", "conv_igemm_f16<128x256,1x1>"},
+        {"conv_igemm_f16<256x128,taps>", "conv_igemm_f16<256x128,1x1>"}, {"conv_igemm_f16<64x64,taps>", "conv_igemm_f16<64x64,1x1>"}};
+    if (mode == 2) return "conv_igemm_f16<128x64,stem>";
+    if (t < 0 || t >= TILE_COUNT) return "conv_igemm_f16<?>";
+    return names[t][mode == 1 ? 1 : 0];
+}
 const char *conv_tile_name(ConvTile t, int mode) {
     static const char *names[TILE_COUNT][2] = {
         {"conv_igemm_f32<128x32,taps>", "conv_igemm_f32<128x32,1x1>"},   {"conv_igemm_f32<128x64,taps>", "conv_igemm_f32<128x64,1x1>"},
@@ -413,11 +458,11 @@ ConvTile conv_pick_tile(int M, int Cout, int K) {
     return TILE_128x32;
 }
 
-template <int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB = 32>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB>
 static hipError_t launch_one(ConvParams p, hipStream_t s) {
     static bool configured = false;
-    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB) * sizeof(float);
-    auto kern = conv_igemm_f32<BM, BN, WGM, WGN, MODE, GENERIC, KB>;
+    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4) * sizeof(float);
+    auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -430,14 +475,14 @@ static hipError_t launch_one(ConvParams p, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <typename T, int BM, int BN, int WGM, int WGN, int KB>
 static hipError_t launch_modes(const ConvParams &p, bool one, bool generic, hipStream_t s) {
-    if (generic) return one ? launch_one<BM, BN, WGM, WGN, MODE_1X1, true>(p, s) : launch_one<BM, BN, WGM, WGN, MODE_TAPS, true>(p, s);
-    return one ? launch_one<BM, BN, WGM, WGN, MODE_1X1, false>(p, s) : launch_one<BM, BN, WGM, WGN, MODE_TAPS, false>(p, s);
+    if (generic) return one ? launch_one<T, BM, BN, WGM, WGN, MODE_1X1, true, KB>(p, s) : launch_one<T, BM, BN, WGM, WGN, MODE_TAPS, true, KB>(p, s);
+    return one ? launch_one<T, BM, BN, WGM, WGN, MODE_1X1, false, KB>(p, s) : launch_one<T, BM, BN, WGM, WGN, MODE_TAPS, false, KB>(p, s);
 }
-template <int BM, int BN, int WGM, int WGN, int KB = 32>
+template <typename T, int BM, int BN, int WGM, int WGN, int KB>
 static hipError_t launch_plain(const ConvParams &p, bool one, hipStream_t s) {
-    return one ? launch_one<BM, BN, WGM, WGN, MODE_1X1, false, KB>(p, s) : launch_one<BM, BN, WGM, WGN, MODE_TAPS, false, KB>(p, s);
+    return one ? launch_one<T, BM, BN, WGM, WGN, MODE_1X1, false, KB>(p, s) : launch_one<T, BM, BN, WGM, WGN, MODE_TAPS, false, KB>(p, s);
 }
 
 hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s) {
@@ -451,26 +496,44 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s) {
     if (!p.ldw) p.ldw = p.Kpad;
     const bool generic = p.scatter || p.rg_out || p.act == ACT_GELU || p.act == ACT_LEAKY || (p.ldc & 3) ||
                          (p.res && (p.ldr & 3));
-    if (p.Cin < BK) {  // stem: NHWC4 frames
-        if (p.Cin != 4 || generic) return hipErrorInvalidValue;
-        return launch_one<128, 64, 2, 2, MODE_SMALLC, false>(p, s);
-    }
-    if (p.Cin % BK != 0) return hipErrorInvalidValue;
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
     if (generic && (tile == TILE_256x128 || tile == TILE_128x256 || tile == TILE_256x256 || tile == TILE_128x128_K16 ||
                     tile == TILE_128x256_K16 || tile == TILE_256x128_K16))
         tile = TILE_128x128;   // the rarely used epilogue paths exist only for the 4-wave tiles
+    if (p.in_f16) {   // fp16 operands (k-step 64); the half-step variants map to their full-step tile
+        if (p.Cin < 64) {   // stem: NHWC8 frames
+            if (p.Cin != 8 || generic) return hipErrorInvalidValue;
+            return launch_one<_Float16, 128, 64, 2, 2, MODE_SMALLC, false, 64>(p, s);
+        }
+        if (p.Cin % 64 != 0 || p.Kpad % 64 != 0) return hipErrorInvalidValue;
+        switch (tile) {
+            case TILE_128x32: return launch_modes<_Float16, 128, 32, 4, 1, 64>(p, one, generic, s);
+            case TILE_128x64: return launch_modes<_Float16, 128, 64, 2, 2, 64>(p, one, generic, s);
+            case TILE_64x64: return launch_modes<_Float16, 64, 64, 2, 2, 64>(p, one, generic, s);
+            case TILE_128x128: return launch_modes<_Float16, 128, 128, 2, 2, 64>(p, one, generic, s);
+            case TILE_128x128_K16: return launch_plain<_Float16, 128, 128, 2, 2, 32>(p, one, s);   // 64-byte rows, 4 blocks/CU
+            case TILE_256x128: case TILE_256x128_K16: return launch_plain<_Float16, 256, 128, 4, 2, 64>(p, one, s);
+            case TILE_128x256: case TILE_128x256_K16: return launch_plain<_Float16, 128, 256, 2, 4, 64>(p, one, s);
+            case TILE_256x256: return launch_plain<_Float16, 256, 256, 2, 4, 64>(p, one, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (p.Cin < BK) {  // stem: NHWC4 frames
+        if (p.Cin != 4 || generic) return hipErrorInvalidValue;
+        return launch_one<float, 128, 64, 2, 2, MODE_SMALLC, false, 32>(p, s);
+    }
+    if (p.Cin % BK != 0) return hipErrorInvalidValue;
     switch (tile) {
-        case TILE_128x32: return launch_modes<128, 32, 4, 1>(p, one, generic, s);
-        case TILE_128x64: return launch_modes<128, 64, 2, 2>(p, one, generic, s);
-        case TILE_128x128: return launch_modes<128, 128, 2, 2>(p, one, generic, s);
-        case TILE_256x128: return launch_plain<256, 128, 4, 2>(p, one, s);
-        case TILE_128x256: return launch_plain<128, 256, 2, 4>(p, one, s);
-        case TILE_256x256: return launch_plain<256, 256, 2, 4>(p, one, s);
-        case TILE_128x128_K16: return launch_plain<128, 128, 2, 2, 16>(p, one, s);
-        case TILE_128x256_K16: return launch_plain<128, 256, 2, 2, 16>(p, one, s);
-        case TILE_256x128_K16: return launch_plain<256, 128, 2, 2, 16>(p, one, s);
-        case TILE_64x64: return launch_modes<64, 64, 2, 2>(p, one, generic, s);
+        case TILE_128x32: return launch_modes<float, 128, 32, 4, 1, 32>(p, one, generic, s);
+        case TILE_128x64: return launch_modes<float, 128, 64, 2, 2, 32>(p, one, generic, s);
+        case TILE_128x128: return launch_modes<float, 128, 128, 2, 2, 32>(p, one, generic, s);
+        case TILE_256x128: return launch_plain<float, 256, 128, 4, 2, 32>(p, one, s);
+        case TILE_128x256: return launch_plain<float, 128, 256, 2, 4, 32>(p, one, s);
+        case TILE_256x256: return launch_plain<float, 256, 256, 2, 4, 32>(p, one, s);
+        case TILE_128x128_K16: return launch_plain<float, 128, 128, 2, 2, 16>(p, one, s);
+        case TILE_128x256_K16: return launch_plain<float, 128, 256, 2, 2, 16>(p, one, s);
+        case TILE_256x128_K16: return launch_plain<float, 256, 128, 2, 2, 16>(p, one, s);
+        case TILE_64x64: return launch_modes<float, 64, 64, 2, 2, 32>(p, one, generic, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -40,6 +40,7 @@ struct HostTensor {
 struct Layer {
     float *w = nullptr, *bias = nullptr;
     int Cin = 0, Cout = 0, R = 1, S = 1, K = 0, Kpad = 0, Cout_pad = 0;
+    bool f16 = false;   // operands (activations + packed weights) are fp16; bias stays fp32
     std::string label;
 };
 
@@ -210,6 +211,19 @@ struct Loader {
         return p;
     }
 
+    void *upload_bytes(const void *src, size_t bytes) {
+        if (rc != HMV_OK) return nullptr;
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            rc = h->fail(HMV_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
+            return nullptr;
+        }
+        h->dev_allocs.push_back(p);
+        return p;
+    }
+
     // BatchNorm (eval) folded to scale/shift in double: resnet.py:59-74
     bool bn_fold(const std::string &prefix, int C, std::vector<double> &scale, std::vector<double> &shift) {
         const HostTensor *g = get(prefix + ".weight", {C}), *b = get(prefix + ".bias", {C});
@@ -227,10 +241,11 @@ struct Loader {
     // Generic finish: `wt(o, k)` supplies the un-scaled weight for output o, packed index k.
     template <typename F>
     void finish(Layer &L, const std::string &label, int Cin, int Cout, int R, int S, int K, F wt,
-                const std::vector<double> *scale, const std::vector<double> *shift, const float *conv_bias) {
+                const std::vector<double> *scale, const std::vector<double> *shift, const float *conv_bias, bool f16 = false) {
         L.label = label;
         L.Cin = Cin; L.Cout = Cout; L.R = R; L.S = S; L.K = K;
-        L.Kpad = round_up(K, 32);
+        L.f16 = f16;
+        L.Kpad = round_up(K, f16 ? 64 : 32);
         L.Cout_pad = round_up(Cout, 256);
         if (rc != HMV_OK) return;
         std::vector<float> w((size_t)L.Cout_pad * L.Kpad, 0.f), b((size_t)L.Cout_pad, 0.f);
@@ -241,13 +256,19 @@ struct Loader {
             if (conv_bias) bb += (double)conv_bias[o] * sc;
             b[o] = (float)bb;
         }
-        L.w = upload(w);
+        if (f16) {   // BN scale is folded in fp32/double first, THEN rounded once to fp16
+            std::vector<_Float16> wh(w.size());
+            for (size_t i = 0; i < w.size(); ++i) wh[i] = (_Float16)w[i];
+            L.w = static_cast<float *>(upload_bytes(wh.data(), wh.size() * sizeof(_Float16)));
+        } else {
+            L.w = upload(w);
+        }
         L.bias = upload(b);
     }
 
     // nn.Conv2d weight OIHW (+ optional bias key) followed by an optional BN
     void conv(Layer &L, const std::string &label, const std::string &wkey, const std::string &bkey, const std::string &bn,
-              int Cout, int Cin, int R, int S, int cin_pad = 0) {
+              int Cout, int Cin, int R, int S, int cin_pad = 0, bool f16 = false) {
         const HostTensor *w = get(wkey, {Cout, Cin, R, S});
         const HostTensor *cb = bkey.empty() ? nullptr : get(bkey, {Cout});
         std::vector<double> sc, sh;
@@ -258,10 +279,11 @@ struct Loader {
         const float *wd = w->data.data();
         auto wt = [=](int o, int k) -> float {
             int c, tap;
-            if (cp >= 32) {   // K order (chunk, r, s, c % 32): conv_igemm.hip
-                const int chunk = k / (32 * R * S), rem = k % (32 * R * S);
-                tap = rem / 32;
-                c = chunk * 32 + rem % 32;
+            if (cp >= 32) {   // K order (chunk, r, s, c % CH), CH = 32 (fp32) / 64 (fp16): conv_igemm.hip
+                const int CH = f16 ? 64 : 32;
+                const int chunk = k / (CH * R * S), rem = k % (CH * R * S);
+                tap = rem / CH;
+                c = chunk * CH + rem % CH;
             } else {          // the stem: (r, s, c)
                 c = k % cp;
                 tap = k / cp;
@@ -270,7 +292,7 @@ struct Loader {
             return wd[(((size_t)o * Cin + c) * R + tap / S) * S + tap % S];
         };
         finish(L, label, cp, Cout, R, S, R * S * cp, wt, has_bn ? &sc : nullptr, has_bn ? &sh : nullptr,
-               cb ? cb->data.data() : nullptr);
+               cb ? cb->data.data() : nullptr, f16);
     }
 
     // nn.Linear weight [out][in] (+ optional bias)
@@ -309,7 +331,7 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     if (cfg->backbone < HMV_RESNET18 || cfg->backbone > HMV_RESNET50_PAPER) return bad("Supports only 18, 34, 50_paper");
     if (cfg->num_views < 1 || cfg->num_views > 48) return bad("num_views must be in [1, 48]");
     if (cfg->fusion_layers < 1 || cfg->fusion_layers % 2 != 1) return bad("num_layers must be an odd number");
-    if (cfg->dtype != HMV_F32) { g_create_err = "only HMV_F32 is built"; return HMV_ERR_UNSUPPORTED; }
+    if (cfg->dtype != HMV_F32 && cfg->dtype != HMV_F16) { g_create_err = "dtype must be HMV_F32 or HMV_F16"; return HMV_ERR_UNSUPPORTED; }
     if (cfg->height < 32 || cfg->width < 32 || cfg->height % 32 || cfg->width % 32)
         return bad("frame height/width must be positive multiples of 32");
     if (cfg->image_size <= 0 || cfg->heatmap_size <= 0) return bad("image_size / heatmap_size must be positive");
@@ -355,9 +377,10 @@ int hmv_finalize_weights(hmv_handle h) {
     Loader L{h};
     const hmv_config &c = h->cfg;
     const int exp = h->paper ? 4 : 1;
+    const bool h16 = c.dtype == HMV_F16;   // conv stack in fp16; heat-map logits, tokens, fusion, decoder stay fp32
 
     // ---- backbone: resnet.py:162-177, 189-203
-    L.conv(h->stem, "stem", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 7, 7, /*cin_pad=*/4);
+    L.conv(h->stem, "stem", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 7, 7, /*cin_pad=*/h16 ? 8 : 4, h16);
     int inpl = 64;
     for (int li = 0; li < 3; ++li) {
         const int planes = 64 << li;
@@ -370,15 +393,15 @@ int hmv_finalize_weights(hmv_handle h) {
             const std::string lab = "layer" + std::to_string(li + 1) + "." + std::to_string(bi);
             const int outc = planes * exp;
             if (h->paper) {
-                L.conv(b.c1, lab + ".conv1", p + ".conv1.weight", "", p + ".bn1", planes, inpl, 1, 1);
-                L.conv(b.c2, lab + ".conv2", p + ".conv2.weight", "", p + ".bn2", planes, planes, 3, 3);
-                L.conv(b.c3, lab + ".conv3", p + ".conv3.weight", "", p + ".bn3", outc, planes, 1, 1);
+                L.conv(b.c1, lab + ".conv1", p + ".conv1.weight", "", p + ".bn1", planes, inpl, 1, 1, 0, h16);
+                L.conv(b.c2, lab + ".conv2", p + ".conv2.weight", "", p + ".bn2", planes, planes, 3, 3, 0, h16);
+                L.conv(b.c3, lab + ".conv3", p + ".conv3.weight", "", p + ".bn3", outc, planes, 1, 1, 0, h16);
             } else {
-                L.conv(b.c1, lab + ".conv1", p + ".conv1.weight", "", p + ".bn1", planes, inpl, 3, 3);
-                L.conv(b.c2, lab + ".conv2", p + ".conv2.weight", "", p + ".bn2", planes, planes, 3, 3);
+                L.conv(b.c1, lab + ".conv1", p + ".conv1.weight", "", p + ".bn1", planes, inpl, 3, 3, 0, h16);
+                L.conv(b.c2, lab + ".conv2", p + ".conv2.weight", "", p + ".bn2", planes, planes, 3, 3, 0, h16);
             }
             b.has_ds = (b.stride != 1 || inpl != outc);
-            if (b.has_ds) L.conv(b.ds, lab + ".downsample", p + ".downsample.0.weight", "", p + ".downsample.1", outc, inpl, 1, 1);
+            if (b.has_ds) L.conv(b.ds, lab + ".downsample", p + ".downsample.0.weight", "", p + ".downsample.1", outc, inpl, 1, 1, 0, h16);
             inpl = outc;
             h->blocks[li].push_back(b);
         }
@@ -386,8 +409,8 @@ int hmv_finalize_weights(hmv_handle h) {
     // ---- pose_net: handmvnet.py:70-86
     const int c0 = c.channels[0];
     if (h->paper) {
-        L.conv(h->pose0, "pose_net.0", "pose_net.0.weight", "pose_net.0.bias", "pose_net.1", 512, c0, 1, 1);
-        L.conv(h->pose1, "pose_net.3", "pose_net.3.weight", "pose_net.3.bias", "", NJ, 512, 1, 1);
+        L.conv(h->pose0, "pose_net.0", "pose_net.0.weight", "pose_net.0.bias", "pose_net.1", 512, c0, 1, 1, 0, h16);
+        L.conv(h->pose1, "pose_net.3", "pose_net.3.weight", "pose_net.3.bias", "", NJ, 512, 1, 1, 0, h16);
     } else {
         // ConvTranspose2d(k4,s2,p1) weight [Cin][Cout][4][4] as 4 sub-pixel 2x2 convs:
         // out[2q+a] takes ky = {3,1} (a=0, window starts at q-1) or {2,0} (a=1, window starts at q)
@@ -400,23 +423,24 @@ int hmv_finalize_weights(hmv_handle h) {
             for (int a = 0; a < 2; ++a)
                 for (int b = 0; b < 2; ++b) {
                     const float *wd = w->data.data();
-                    auto wt = [=](int o, int k) -> float {   // K order (chunk, r, s, c % 32)
-                        const int chunk = k / (32 * 4), rem = k % (32 * 4), tap = rem / 32;
-                        const int ci = chunk * 32 + rem % 32, r = tap / 2, s = tap % 2;
+                    const int CH = h16 ? 64 : 32;
+                    auto wt = [=](int o, int k) -> float {   // K order (chunk, r, s, c % CH)
+                        const int chunk = k / (CH * 4), rem = k % (CH * 4), tap = rem / CH;
+                        const int ci = chunk * CH + rem % CH, r = tap / 2, s = tap % 2;
                         return wd[(((size_t)ci * 128 + o) * 4 + kmap[a][r]) * 4 + kmap[b][s]];
                     };
                     L.finish(h->deconv[a * 2 + b], "pose_net.0.phase" + std::to_string(a * 2 + b), c0, 128, 2, 2, 4 * c0, wt,
-                             &sc, &sh, cb->data.data());
+                             &sc, &sh, cb->data.data(), h16);
                 }
         }
-        L.conv(h->pose1, "pose_net.3", "pose_net.3.weight", "pose_net.3.bias", "pose_net.4", 64, 128, 3, 3);
-        L.conv(h->pose2, "pose_net.6", "pose_net.6.weight", "pose_net.6.bias", "", NJ, 64, 3, 3);
+        L.conv(h->pose1, "pose_net.3", "pose_net.3.weight", "pose_net.3.bias", "pose_net.4", 64, 128, 3, 3, 0, h16);
+        L.conv(h->pose2, "pose_net.6", "pose_net.6.weight", "pose_net.6.bias", "", NJ, 64, 3, 3, 0, h16);
     }
     // ---- sample nets: nets.py:24-31
     for (int i = 0; i < c.n_levels; ++i) {
         const std::string p = "sample_nets." + std::to_string(i) + ".conv";
         L.conv(h->sample[i], "sample_nets." + std::to_string(i), p + ".0.weight", p + ".0.bias", p + ".1", c.channels[i] / 2,
-               c.channels[i], 1, 1);
+               c.channels[i], 1, 1, 0, h16);
     }
     // ---- fusion: layers.py:177-200
     const int d = h->d;
@@ -616,10 +640,11 @@ struct Runner {
     // One conv / GEMM launch.  in: NHWC [N][H][W][L.Cin] ; returns output dims through Ho/Wo.
     void conv(const Layer &L, const float *in, int N, int H, int W, int stride, int pad_h, int pad_w, float *out, int ldc,
               const float *res, int ldr, int act, int Ho, int Wo, int rg_out = 0, int rg_in = 0, int scatter = 0, int ooy = 0,
-              int oox = 0) {
+              int oox = 0, bool out_f16 = false) {
         if (dry || rc != HMV_OK) return;
         ConvParams p{};
         p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res; p.out = out;
+        p.in_f16 = L.f16; p.out_f16 = out_f16; p.res_f16 = L.f16 && res != nullptr;   // a residual always has the layer's dtype
         p.N = N; p.H = H; p.W = W; p.Cin = L.Cin;
         p.Ho = Ho; p.Wo = Wo; p.Cout = L.Cout;
         p.R = L.R; p.S = L.S; p.stride = stride; p.pad_h = pad_h; p.pad_w = pad_w;
@@ -638,10 +663,11 @@ struct Runner {
                 h->prof.push_back(r);
             }
             pr = &h->prof[h->prof_used++];
-            pr->name = conv_tile_name(tile, L.Cin < 32 ? 2 : ((L.R == 1 && L.S == 1 && pad_h == 0 && pad_w == 0) ? 1 : 0));
+            const int mode_ = L.Cin < 32 ? 2 : ((L.R == 1 && L.S == 1 && pad_h == 0 && pad_w == 0) ? 1 : 0);
+            pr->name = L.f16 ? conv_tile_name_f16(tile, mode_) : conv_tile_name(tile, mode_);
             pr->label = L.label;
             // algorithmic FLOPs: the real (un-padded) reduction length; the stem's 4th channel is padding
-            const double kreal = (L.Cin == 4) ? (double)L.R * L.S * 3 : (double)L.K;
+            const double kreal = (L.Cin < 32) ? (double)L.R * L.S * 3 : (double)L.K;
             pr->flops = 2.0 * (double)p.M * (double)L.Cout * kreal;
             check(hipEventRecord(pr->e0, s), "hipEventRecord");
         }
@@ -661,18 +687,24 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     const hmv_config &c = h->cfg;
     const int V = c.num_views, N = B * V, H = c.height, W = c.width;
     const int d = h->d, ldt = h->ldt;
+    // fp16 path: the conv stack (stem .. pose_net / sample convs) stores activations as fp16; heat-map logits,
+    // coordinates, tokens, fusion and decoder stay fp32.  ACT(n) = arena floats for n activation elements.
+    const bool h16 = c.dtype == HMV_F16;
+#define ACT(n) ((h16) ? ((size_t)(n) + 1) / 2 : (size_t)(n))
 #define LAUNCH(expr) do { if (!dry && R.rc == HMV_OK) R.check((expr), #expr); } while (0)
 
     // ---- stem: conv1 7x7 s2 + BN + ReLU, maxpool 3x3 s2 (resnet.py:218-221)
-    float *in4 = R.alloc((size_t)N * H * W * 4);
-    LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
+    float *in4 = R.alloc((size_t)N * H * W * 4);   // NHWC4 fp32 and NHWC8 fp16 are both 16 bytes per pixel
+    if (h16) LAUNCH(launch_nchw_to_nhwc8_f16(x, in4, N, H, W, s));
+    else LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
     const int H1 = (H + 6 - 7) / 2 + 1, W1 = (W + 6 - 7) / 2 + 1;
-    float *c1 = R.alloc((size_t)N * H1 * W1 * 64);
-    R.conv(h->stem, in4, N, H, W, 2, 3, 3, c1, 64, nullptr, 0, ACT_RELU, H1, W1);
+    float *c1 = R.alloc(ACT((size_t)N * H1 * W1 * 64));
+    R.conv(h->stem, in4, N, H, W, 2, 3, 3, c1, 64, nullptr, 0, ACT_RELU, H1, W1, 0, 0, 0, 0, 0, h16);
     R.release(in4);
     int hh = (H1 + 2 - 3) / 2 + 1, ww = (W1 + 2 - 3) / 2 + 1, C = 64;
-    float *cur = R.alloc((size_t)N * hh * ww * 64);
-    LAUNCH(launch_maxpool3s2(c1, cur, N, H1, W1, 64, hh, ww, s));
+    float *cur = R.alloc(ACT((size_t)N * hh * ww * 64));
+    if (h16) LAUNCH(launch_maxpool3s2_f16(c1, cur, N, H1, W1, 64, hh, ww, s));
+    else LAUNCH(launch_maxpool3s2(c1, cur, N, H1, W1, 64, hh, ww, s));
     R.release(c1);
 
     // ---- residual layers (resnet.py:223-239; Bottleneck 124-144; BasicBlock 90-106)
@@ -687,36 +719,36 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
             if (h->paper) {
                 const int planes = b.c1.Cout;
                 outc = b.c3.Cout;
-                float *t1 = R.alloc((size_t)N * hh * ww * planes);
-                R.conv(b.c1, cur, N, hh, ww, 1, 0, 0, t1, planes, nullptr, 0, ACT_RELU, hh, ww);
-                float *t2 = R.alloc((size_t)N * ho * wo * planes);
-                R.conv(b.c2, t1, N, hh, ww, b.stride, 1, 1, t2, planes, nullptr, 0, ACT_RELU, ho, wo);
+                float *t1 = R.alloc(ACT((size_t)N * hh * ww * planes));
+                R.conv(b.c1, cur, N, hh, ww, 1, 0, 0, t1, planes, nullptr, 0, ACT_RELU, hh, ww, 0, 0, 0, 0, 0, h16);
+                float *t2 = R.alloc(ACT((size_t)N * ho * wo * planes));
+                R.conv(b.c2, t1, N, hh, ww, b.stride, 1, 1, t2, planes, nullptr, 0, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, h16);
                 R.release(t1);
                 const float *res = cur;
                 float *dsb = nullptr;
                 if (b.has_ds) {
-                    dsb = R.alloc((size_t)N * ho * wo * outc);
-                    R.conv(b.ds, cur, N, hh, ww, b.stride, 0, 0, dsb, outc, nullptr, 0, ACT_NONE, ho, wo);
+                    dsb = R.alloc(ACT((size_t)N * ho * wo * outc));
+                    R.conv(b.ds, cur, N, hh, ww, b.stride, 0, 0, dsb, outc, nullptr, 0, ACT_NONE, ho, wo, 0, 0, 0, 0, 0, h16);
                     res = dsb;
                 }
-                y = R.alloc((size_t)N * ho * wo * outc);
-                R.conv(b.c3, t2, N, ho, wo, 1, 0, 0, y, outc, res, outc, ACT_RELU, ho, wo);
+                y = R.alloc(ACT((size_t)N * ho * wo * outc));
+                R.conv(b.c3, t2, N, ho, wo, 1, 0, 0, y, outc, res, outc, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, h16);
                 R.release(t2);
                 R.release(dsb);
             } else {
                 const int planes = b.c1.Cout;
                 outc = planes;
-                float *t1 = R.alloc((size_t)N * ho * wo * planes);
-                R.conv(b.c1, cur, N, hh, ww, b.stride, 1, 1, t1, planes, nullptr, 0, ACT_RELU, ho, wo);
+                float *t1 = R.alloc(ACT((size_t)N * ho * wo * planes));
+                R.conv(b.c1, cur, N, hh, ww, b.stride, 1, 1, t1, planes, nullptr, 0, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, h16);
                 const float *res = cur;
                 float *dsb = nullptr;
                 if (b.has_ds) {
-                    dsb = R.alloc((size_t)N * ho * wo * outc);
-                    R.conv(b.ds, cur, N, hh, ww, b.stride, 0, 0, dsb, outc, nullptr, 0, ACT_NONE, ho, wo);
+                    dsb = R.alloc(ACT((size_t)N * ho * wo * outc));
+                    R.conv(b.ds, cur, N, hh, ww, b.stride, 0, 0, dsb, outc, nullptr, 0, ACT_NONE, ho, wo, 0, 0, 0, 0, 0, h16);
                     res = dsb;
                 }
-                y = R.alloc((size_t)N * ho * wo * outc);
-                R.conv(b.c2, t1, N, ho, wo, 1, 1, 1, y, outc, res, outc, ACT_RELU, ho, wo);
+                y = R.alloc(ACT((size_t)N * ho * wo * outc));
+                R.conv(b.c2, t1, N, ho, wo, 1, 1, 1, y, outc, res, outc, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, h16);
                 R.release(t1);
                 R.release(dsb);
             }
@@ -732,27 +764,30 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     }
     float *feat0 = level[2];
     const int fh = lh[2], fw = lw[2];
-    if (h->capture && !dry && h->cap_feat0) LAUNCH(launch_nhwc_to_nchw(feat0, h->cap_feat0, N, fh, fw, lc[2], s));
+    if (h->capture && !dry && h->cap_feat0) {
+        if (h16) LAUNCH(launch_nhwc_f16_to_nchw(feat0, h->cap_feat0, N, fh, fw, lc[2], s));
+        else LAUNCH(launch_nhwc_to_nchw(feat0, h->cap_feat0, N, fh, fw, lc[2], s));
+    }
 
     // ---- pose_net (handmvnet.py:70-86, 180) -> channels-last heat map with row stride 32
     int hmh, hmw;
     float *hm;
     if (h->paper) {
         hmh = fh; hmw = fw;
-        float *ph = R.alloc((size_t)N * fh * fw * 512);
-        R.conv(h->pose0, feat0, N, fh, fw, 1, 0, 0, ph, 512, nullptr, 0, ACT_RELU, fh, fw);
-        hm = R.alloc((size_t)N * hmh * hmw * 32);
+        float *ph = R.alloc(ACT((size_t)N * fh * fw * 512));
+        R.conv(h->pose0, feat0, N, fh, fw, 1, 0, 0, ph, 512, nullptr, 0, ACT_RELU, fh, fw, 0, 0, 0, 0, 0, h16);
+        hm = R.alloc((size_t)N * hmh * hmw * 32);   // heat-map logits are ALWAYS fp32 (x1000 temperature)
         R.conv(h->pose1, ph, N, fh, fw, 1, 0, 0, hm, 32, nullptr, 0, ACT_NONE, fh, fw);
         R.release(ph);
     } else {
         hmh = 2 * fh; hmw = 2 * fw;
-        float *p0 = R.alloc((size_t)N * hmh * hmw * 128);
+        float *p0 = R.alloc(ACT((size_t)N * hmh * hmw * 128));
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 2; ++b)
                 R.conv(h->deconv[a * 2 + b], feat0, N, fh, fw, 1, 1 - a, 1 - b, p0, 128, nullptr, 0, ACT_RELU, fh, fw, 0, 0,
-                       /*scatter=*/1, a, b);
-        float *p1 = R.alloc((size_t)N * hmh * hmw * 64);
-        R.conv(h->pose1, p0, N, hmh, hmw, 1, 1, 1, p1, 64, nullptr, 0, ACT_RELU, hmh, hmw);
+                       /*scatter=*/1, a, b, h16);
+        float *p1 = R.alloc(ACT((size_t)N * hmh * hmw * 64));
+        R.conv(h->pose1, p0, N, hmh, hmw, 1, 1, 1, p1, 64, nullptr, 0, ACT_RELU, hmh, hmw, 0, 0, 0, 0, 0, h16);
         R.release(p0);
         hm = R.alloc((size_t)N * hmh * hmw * 32);
         R.conv(h->pose2, p1, N, hmh, hmw, 1, 1, 1, hm, 32, nullptr, 0, ACT_NONE, hmh, hmw);
@@ -770,8 +805,8 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     int col0 = 0;
     for (int i = 0; i < c.n_levels; ++i) {
         const int li = 2 - i, Ci = lc[li], co = Ci / 2;
-        float *g = R.alloc((size_t)N * NJ * 4 * Ci);
-        LAUNCH(launch_sample_gather(level[li], N, lh[li], lw[li], Ci, coords, g, s));
+        float *g = R.alloc(ACT((size_t)N * NJ * 4 * Ci));
+        LAUNCH(launch_sample_gather(level[li], N, lh[li], lw[li], Ci, coords, g, s, h16 ? 2 : 4));
         float *s4 = R.alloc((size_t)N * NJ * 4 * co);
         R.gemm(h->sample[i], g, N * NJ * 4, s4, co, nullptr, 0, ACT_RELU);
         R.release(g);
@@ -845,6 +880,7 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         R.release(g1);
     }
 #undef LAUNCH
+#undef ACT
     return R.rc;
 }
 

@@ -12,12 +12,13 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_LEAKY = 3 };
 // A[m][k] is gathered on the fly from an NHWC tensor: m = (img, ho, wo), k = (chunk, r, s, c % 32).
 // A plain row-major GEMM is the special case H = W = R = S = 1, N = M, Cin = K.
 struct ConvParams {
-    const float *in;    // NHWC [N][H][W][Cin]
-    const float *wgt;   // [Cout_pad][Kpad], zero padded; K ordered (c / 32, r, s, c % 32) for Cin >= 32
-                        // and (r, s, c) for the 4-channel stem
-    const float *bias;  // [Cout_pad] (folded BN shift + conv bias), never null
-    const float *res;   // residual, row-major [M'][ldr] or null
-    float *out;         // [M''][ldc]
+    const void *in;     // NHWC [N][H][W][Cin], fp32 or fp16 (in_f16)
+    const void *wgt;    // [Cout_pad][Kpad], zero padded, same element type as `in`; K ordered
+                        // (c / CH, r, s, c % CH) with CH = 32 (fp32) / 64 (fp16), and (r, s, c) for the stem
+    const float *bias;  // [Cout_pad] fp32 (folded BN shift + conv bias), never null
+    const void *res;    // residual, row-major [M'][ldr] or null; fp16 if res_f16
+    void *out;          // [M''][ldc]; fp16 if out_f16
+    int in_f16, res_f16, out_f16;
     int N, H, W, Cin;
     int Ho, Wo, Cout;
     int R, S, stride, pad_h, pad_w;
@@ -39,6 +40,7 @@ enum ConvTile { TILE_128x32 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x128
                 TILE_128x128_K16 = 6, TILE_128x256_K16 = 7, TILE_256x128_K16 = 8, TILE_64x64 = 9, TILE_COUNT = 10 };
 int conv_tile_bn(ConvTile t);                       // N-tile width of a tile config
 const char *conv_tile_name(ConvTile t, int mode);   // mode: 0 taps, 1 1x1/GEMM, 2 stem
+const char *conv_tile_name_f16(ConvTile t, int mode);
 ConvTile conv_pick_tile(int M, int Cout, int K);
 // fills mtiles/ntiles and launches
 hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s);
@@ -52,7 +54,11 @@ hipError_t launch_soft_argmax(const float *hm, int ld, int N, int h, int w, floa
                               float image_size, float heatmap_size, float *hm_nchw, hipStream_t s);
 // gathers the 4 bilinear neighbours of every joint: out [(n*21+j)*4 + t][C] (zeros when out of range)
 hipError_t launch_sample_gather(const float *feat, int N, int H, int W, int C, const float *coords, float *out,
-                                hipStream_t s);
+                                hipStream_t s, int elem_bytes = 4);
+// fp16 path (BASELINE configs[4])
+hipError_t launch_nchw_to_nhwc8_f16(const float *x, void *out, int N, int H, int W, hipStream_t s);
+hipError_t launch_maxpool3s2_f16(const void *in, void *out, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
+hipError_t launch_nhwc_f16_to_nchw(const void *in, float *out, int N, int H, int W, int C, hipStream_t s);
 // tokens[(n*21+j)][col0 + c] = sum_t w_t * s[(n*21+j)*4+t][c]
 hipError_t launch_sample_blend(const float *s4, int lds4, int C, int N, int H, int W, const float *coords,
                                float *tokens, int ldt, int col0, hipStream_t s);

@@ -37,6 +37,62 @@ hipError_t launch_nchw_to_nhwc4(const float *x, float *out, int N, int H, int W,
     return hipGetLastError();
 }
 
+// fp16 path: NCHW fp32 frames -> NHWC8 fp16 (3 real channels + 5 zeros = one 16-byte tap)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ void nchw_to_nhwc8_f16_kernel(const float *__restrict__ x, f16x8 *__restrict__ out, int HW, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const size_t n = i / HW, pix = i - n * HW;
+        const float *src = x + n * 3 * (size_t)HW + pix;
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        v[0] = (_Float16)src[0]; v[1] = (_Float16)src[HW]; v[2] = (_Float16)src[2 * (size_t)HW];
+        out[i] = v;
+    }
+}
+hipError_t launch_nchw_to_nhwc8_f16(const float *x, void *out, int N, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)N * H * W;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(nchw_to_nhwc8_f16_kernel, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<f16x8 *>(out), H * W, total);
+    return hipGetLastError();
+}
+
+__global__ void maxpool3s2_f16_kernel(const f16x8 *__restrict__ in, f16x8 *__restrict__ out, int H, int W, int C8, int Ho,
+                                      int Wo, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % C8);
+        size_t t = i / C8;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const size_t n = t / Ho;
+        f16x8 m;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = (_Float16)(-65504.f);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = ho * 2 - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int wi = wo * 2 - 1 + q;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                m = __builtin_elementwise_max(m, in[((n * H + hi) * W + wi) * C8 + c]);
+            }
+        }
+        out[i] = m;
+    }
+}
+hipError_t launch_maxpool3s2_f16(const void *in, void *out, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool3s2_f16_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const f16x8 *>(in),
+                       reinterpret_cast<f16x8 *>(out), H, W, C / 8, Ho, Wo, total);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ MaxPool2d(3, stride 2, pad 1), NHWC
 // resnet.py:165,221
 __global__ void maxpool3s2_kernel(const f32x4 *__restrict__ in, f32x4 *__restrict__ out, int H, int W, int C4, int Ho,
@@ -162,9 +218,10 @@ __global__ void sample_gather_kernel(const f32x4 *__restrict__ feat, int H, int 
     }
 }
 hipError_t launch_sample_gather(const float *feat, int N, int H, int W, int C, const float *coords, float *out,
-                                hipStream_t s) {
+                                hipStream_t s, int elem_bytes) {
+    // the kernel copies 16-byte chunks, so it is dtype-agnostic: C * elem_bytes / 16 chunks per pixel
     hipLaunchKernelGGL(sample_gather_kernel, dim3(N * 21), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(feat), H, W,
-                       C / 4, coords, reinterpret_cast<f32x4 *>(out));
+                       C * elem_bytes / 16, coords, reinterpret_cast<f32x4 *>(out));
     return hipGetLastError();
 }
 
@@ -466,6 +523,23 @@ __global__ void nhwc_to_nchw_kernel(const float *__restrict__ in, float *__restr
         const size_t n = t / C;
         out[i] = in[(n * HW + p) * C + c];
     }
+}
+__global__ void nhwc_f16_to_nchw_kernel(const _Float16 *__restrict__ in, float *__restrict__ out, int HW, int C, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int p = (int)(i % HW);
+        const size_t t = i / HW;
+        const int c = (int)(t % C);
+        const size_t n = t / C;
+        out[i] = (float)in[(n * HW + p) * C + c];
+    }
+}
+hipError_t launch_nhwc_f16_to_nchw(const void *in, float *out, int N, int H, int W, int C, hipStream_t s) {
+    const size_t total = (size_t)N * H * W * C;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nhwc_f16_to_nchw_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const _Float16 *>(in), out, H * W, C, total);
+    return hipGetLastError();
 }
 hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t s) {
     const size_t total = (size_t)N * H * W * C;

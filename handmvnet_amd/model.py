@@ -46,6 +46,7 @@ class HandMvNet(torch.nn.Module):
         # the reference constructor random-initialises; ours does so deterministically
         self._weights: "OrderedDict[str, np.ndarray]" = synth_state_dict(self.cfg, init_seed)
         self._engines: Dict[tuple, ctypes.c_void_p] = {}
+        self._dtype = 0   # 0 = fp32 (HMV_F32), 1 = fp16 conv stack (HMV_F16, BASELINE configs[4])
         self._capture = False
         self._profiling = False
         self._last_key: Optional[tuple] = None
@@ -84,6 +85,20 @@ class HandMvNet(torch.nn.Module):
         self._drop_engines()
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
+    def half(self):
+        """torch-style switch to the fp16 path: conv stack in fp16 storage + fp16 MFMA (fp32 accumulate);
+        heat-map logits, soft-argmax, tokens, fusion and decoder stay fp32; inputs/outputs stay fp32."""
+        if self._dtype != 1:
+            self._dtype = 1
+            self._drop_engines()
+        return self
+
+    def float(self):
+        if self._dtype != 0:
+            self._dtype = 0
+            self._drop_engines()
+        return self
+
     # ------------------------------------------------------------------ engine management
     def _drop_engines(self):
         if self._engines:
@@ -99,7 +114,7 @@ class HandMvNet(torch.nn.Module):
             pass
 
     def _engine(self, height: int, width: int, device_index: int):
-        key = (height, width, device_index)
+        key = (height, width, device_index, self._dtype)
         if key in self._engines:
             return self._engines[key]
         lib = _lib.load()
@@ -113,7 +128,7 @@ class HandMvNet(torch.nn.Module):
         c.num_views, c.height, c.width = cfg.num_views, height, width
         c.image_size, c.heatmap_size = cfg.image_size, cfg.heatmap_size
         c.pos_enc, c.fusion_layers, c.decoder = cfg.pos_mask, cfg.fusion_layers, int(cfg.use_gcn)
-        c.dtype, c.device = 0, device_index
+        c.dtype, c.device = self._dtype, device_index
         h = ctypes.c_void_p()
         _lib.check(lib.hmv_create(ctypes.byref(c), ctypes.byref(h)))
         try:
@@ -174,7 +189,7 @@ class HandMvNet(torch.nn.Module):
                                          it.data_ptr() if it is not None else None, out_crop.data_ptr(), out_cam.data_ptr(),
                                          out_hm.data_ptr(), ctypes.c_void_p(stream))
         _lib.check(rc, h)
-        self._last_key = (hh, ww, dev.index if dev.index is not None else torch.cuda.current_device(), batch)
+        self._last_key = (hh, ww, dev.index if dev.index is not None else torch.cuda.current_device(), batch, self._dtype)
         return {"joints_crop_img": out_crop, "joints_cam": out_cam, "heatmap": out_hm}
 
     # ------------------------------------------------------------------ introspection (tests / bench)
@@ -184,8 +199,8 @@ class HandMvNet(torch.nn.Module):
             _lib.load().hmv_set_capture(h, int(enable))
 
     def read_stage(self, name: str) -> torch.Tensor:
-        hh, ww, idx, batch = self._last_key
-        h = self._engines[(hh, ww, idx)]
+        hh, ww, idx, batch, dt = self._last_key
+        h = self._engines[(hh, ww, idx, dt)]
         n, d, cfg = batch * self.num_views, self.feat_dim, self.cfg
         fdiv = 8 if cfg.is_paper else 16
         shape = {"feat0": (n, cfg.backbone_channels[0], hh // fdiv, ww // fdiv), "coords_hm": (n, 21, 2),
@@ -202,8 +217,8 @@ class HandMvNet(torch.nn.Module):
 
     def profile_records(self):
         """Per-launch records of the last forward (caller must have synchronised)."""
-        hh, ww, idx, _ = self._last_key
-        h = self._engines[(hh, ww, idx)]
+        hh, ww, idx, _, dt = self._last_key
+        h = self._engines[(hh, ww, idx, dt)]
         lib = _lib.load()
         recs = []
         for i in range(lib.hmv_profile_count(h)):

@@ -35,7 +35,9 @@ enum { HMV_RESNET18 = 0, HMV_RESNET34 = 1, HMV_RESNET50_PAPER = 2 };
 enum { HMV_POS2D = 1, HMV_POS_CROP = 2, HMV_POS_SIN = 4 };
 /* model_params["use_gcn"]: JointsDecoderNN | JointsDecoderGCN (handmvnet.py:152-155) */
 enum { HMV_DECODER_NN = 0, HMV_DECODER_GCN = 1 };
-enum { HMV_F32 = 0 };
+/* HMV_F16 = BASELINE configs[4]: conv stack in fp16 storage + fp16 MFMA with fp32 accumulation; heat-map
+ * logits, soft-argmax, tokens, fusion transformer and decoder stay fp32.  I/O buffers are fp32 either way. */
+enum { HMV_F32 = 0, HMV_F16 = 1 };
 
 typedef struct hmv_config {
     int32_t struct_size;   /* sizeof(hmv_config), ABI guard */
@@ -49,7 +51,7 @@ typedef struct hmv_config {
     int32_t pos_enc;       /* bitmask of HMV_POS* */
     int32_t fusion_layers; /* model_params["fusion_layers"], odd */
     int32_t decoder;       /* HMV_DECODER_* */
-    int32_t dtype;         /* HMV_F32 */
+    int32_t dtype;         /* HMV_F32 | HMV_F16 */
     int32_t device;        /* HIP device ordinal */
 } hmv_config;
 

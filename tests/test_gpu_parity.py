@@ -177,3 +177,38 @@ def test_state_dict_errors_match_reference_behaviour():
     m.load_state_dict(legacy, strict=True)           # eval.py:27-52 remap
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 3, 64, 64, device="cuda"))   # 3 frames cannot be viewed as [-1, 2, ...]
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: the fp16 path (model.half()): conv stack in fp16 storage + fp16 MFMA
+# with fp32 accumulation; heat-map logits, soft-argmax, tokens, fusion and decoder stay fp32.
+# Its tolerance is stated SEPARATELY from the fp32 north-star bar (hard part 1):
+#   * dense tensors (backbone features, heat maps): <= 3e-3 rel-L2 (fp16 has a 2^-11 mantissa and the
+#     rounding noise of ~50 layers accumulates to ~9e-4 measured);
+#   * heat-map coordinates: median error <= 0.02 px, and at most 6 % of the coordinates may move by more
+#     than half a pixel -- soft_argmax_2d multiplies logits by 1000, so a 1e-3 heat-map error flips the
+#     winner of near-tied peaks (the synthetic random-weight heat maps have many near ties; measured
+#     flip rate 0-2.8 %);
+#   * joints_cam: <= 0.15 rel-L2, dominated by exactly those flips (measured 5e-4 .. 7.6e-2).
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tiny_r50", "tiny_r18", "cfg1_r50_v4_128", "cfg2s_r18_v4_256", "cfg3s_r50_v8_256",
+                                  "r50_wocam_nn", "r34_onelevel", "r18_single_view"])
+def test_fp16_path_within_its_stated_tolerance(name):
+    m, cfg, sd, (x, bbox, intr), fx = _model(name)
+    m.half()
+    got = _run(m, x, bbox, intr)
+    feat = rel_l2(got["feat0"].reshape(-1)[fx["feat0_idx"]], fx["feat0_val"])
+    hm = rel_l2(got["heatmap"].reshape(-1)[fx["heatmap_idx"]], fx["heatmap_val"])
+    dc = np.abs(got["coords_hm"] - fx["coords_hm"])
+    cam = rel_l2(got["joints_cam"], fx["joints_cam"])
+    rep = {"feat0": feat, "heatmap": hm, "coord_median_px": float(np.median(dc)), "coord_flip_frac": float((dc > 0.5).mean()),
+           "joints_cam": cam}
+    print(name, rep)
+    assert feat <= 3e-3 and hm <= 3e-3, rep
+    assert rep["coord_median_px"] <= 0.02 and rep["coord_flip_frac"] <= 0.06, rep
+    assert cam <= 0.15, rep
+    assert np.isfinite(got["joints_cam"]).all()
+    # and the fp16 engine really is a different numerical path from the fp32 one
+    m.float()
+    ref32 = _run(m, x, bbox, intr)
+    assert rel_l2(ref32["feat0"], got["feat0"]) > 1e-5

@@ -24,9 +24,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def family(name: str) -> str:
-    m = re.match(r"void hmv::conv_igemm_f32<(\d+), (\d+), \d+, \d+, (\d), (?:false|true)>", name)
+    """rocprofv3 symbol -> the kernel family name bench.py / the engine use (one symbol per family)."""
+    m = re.match(r"void hmv::conv_igemm<(float|_Float16), (\d+), (\d+), \d+, \d+, (\d), (?:false|true), (\d+)>", name)
     if m:
-        return f"conv_igemm_f32<{m.group(1)}x{m.group(2)}," + {"0": "taps", "1": "1x1", "2": "stem"}[m.group(3)] + ">"
+        t = "f32" if m.group(1) == "float" else "f16"
+        k16 = ",k16" if (t == "f32" and m.group(5) == "16") else ""
+        return f"conv_igemm_{t}<{m.group(2)}x{m.group(3)}{k16}," + {"0": "taps", "1": "1x1", "2": "stem"}[m.group(4)] + ">"
     return re.sub(r"\(.*", "", name).replace("void ", "").replace("hmv::", "")
 
 

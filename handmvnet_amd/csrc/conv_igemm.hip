@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
         hi0[i] = ok ? ho * p.stride - p.pad_h : -(1 << 28);   // out-of-range rows fail every bounds test
         wi0[i] = wo * p.stride - p.pad_w;
         if (MODE == MODE_1X1) {
+            if (ok) { hi0[i] >>= p.up; wi0[i] >>= p.up; }   // nearest-neighbour upsampled input (HRNet fuse)
             aptr[i] = ok ? base + (hi0[i] * p.W + wi0[i]) * p.lda + EPC * kqs : zero;
             astep[i] = ok ? KB : 0;
         } else if (MODE == MODE_TAPS) {
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
             const int col = n0 + 4 * c4;
             // columns [Cout, round4(Cout)) hold exact zeros (zero-padded weights and bias): writing them is
             // harmless whenever the row stride leaves room, which lets Cout = 21 use vector stores too.
-            const int cend = p.Cout + 3 < p.ldc ? ((p.Cout + 3) & ~3) : p.ldc;
+            const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 3) & ~3);
             if (col < cend) {
                 const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + col);
                 const bool has_res = p.res != nullptr;

@@ -26,6 +26,8 @@ namespace {
 
 constexpr int NJ = 21, HEADS = 8, DHEAD = 128, INNER = HEADS * DHEAD;
 const int kBlocks[3][4] = {{2, 2, 2, 2}, {3, 4, 6, 3}, {3, 4, 6, 3}};
+const int kHrChannels[2][4] = {{40, 80, 160, 320}, {64, 128, 256, 512}};   // hrnet.py:430-447
+inline int cpad(int c) { return (c + 31) / 32 * 32; }                      // padded NHWC channel stride
 
 std::string g_create_err;
 
@@ -48,6 +50,19 @@ struct Block {
     Layer c1, c2, c3, ds;
     bool has_ds = false;
     int stride = 1;
+};
+
+// HRNet (backbones/hrnet.py): one HighResolutionModule = per-branch BasicBlocks + the fuse layers
+struct HrModule {
+    Layer br[4][4][2];             // [branch][block][conv1 | conv2]
+    std::vector<Layer> fuse[4][4]; // [i][j]: j > i one 1x1 conv; j < i a chain of (i - j) stride-2 3x3 convs
+};
+struct HrNet {
+    Layer conv1, conv2;            // stem: two 3x3 stride-2 convs
+    std::vector<Block> layer1;     // 4 Bottlenecks (planes 64)
+    std::vector<Layer> trans[3][4];
+    std::vector<HrModule> stage[3];
+    int ch[4] = {0, 0, 0, 0};
 };
 
 struct AttnLayer {
@@ -130,10 +145,12 @@ struct hmv_engine {
     bool paper = false;
 
     Layer stem;
+    HrNet hr;
+    bool hrnet = false;
     std::vector<Block> blocks[3];
     Layer pose0, pose1, pose2;   // r50: pose0 (1x1 1024->512), pose1 (1x1 512->21); r18/34: pose1 (3x3 128->64), pose2 (3x3 64->21)
     Layer deconv[4];             // r18/34 ConvTranspose2d as 4 sub-pixel 2x2 convs (phase a*2+b)
-    Layer sample[3];
+    Layer sample[4];
     std::vector<AttnLayer> attn;
     Layer gcn[3];
     float *gcn_bias[3] = {nullptr, nullptr, nullptr};
@@ -328,7 +345,7 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     auto bad = [&](const char *m) { g_create_err = m; return HMV_ERR_ARG; };
     if (!cfg || !out) return bad("null argument");
     if (cfg->struct_size != (int32_t)sizeof(hmv_config)) return bad("hmv_config.struct_size mismatch (ABI)");
-    if (cfg->backbone < HMV_RESNET18 || cfg->backbone > HMV_RESNET50_PAPER) return bad("Supports only 18, 34, 50_paper");
+    if (cfg->backbone < HMV_RESNET18 || cfg->backbone > HMV_HRNET_W64) return bad("Supports only 18, 34, 50_paper (resnet) and w40, w64 (hrnet)");
     if (cfg->num_views < 1 || cfg->num_views > 48) return bad("num_views must be in [1, 48]");
     if (cfg->fusion_layers < 1 || cfg->fusion_layers % 2 != 1) return bad("num_layers must be an odd number");
     if (cfg->dtype != HMV_F32 && cfg->dtype != HMV_F16) { g_create_err = "dtype must be HMV_F32 or HMV_F16"; return HMV_ERR_UNSUPPORTED; }
@@ -336,9 +353,12 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
         return bad("frame height/width must be positive multiples of 32");
     if (cfg->image_size <= 0 || cfg->heatmap_size <= 0) return bad("image_size / heatmap_size must be positive");
     const bool paper = cfg->backbone == HMV_RESNET50_PAPER;
-    if (cfg->n_levels < 1 || cfg->n_levels > (paper ? 1 : 3)) return bad("backbone_channels has too many levels for this backbone");
+    const bool hrnet = cfg->backbone >= HMV_HRNET_W40;
+    if (cfg->n_levels < 1 || cfg->n_levels > (hrnet ? 4 : (paper ? 1 : 3))) return bad("backbone_channels has too many levels for this backbone");
     for (int i = 0; i < cfg->n_levels; ++i)
-        if (cfg->channels[i] != backbone_level_channels(*cfg, 2 - i)) return bad("backbone_channels do not match the backbone");
+        if (cfg->channels[i] != (hrnet ? kHrChannels[cfg->backbone - HMV_HRNET_W40][i] : backbone_level_channels(*cfg, 2 - i)))
+            return bad("backbone_channels do not match the backbone");
+    if (hrnet && cfg->dtype != HMV_F32) { g_create_err = "the fp16 path is built for the ResNet backbones only"; return HMV_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g_create_err = "no HIP device: libhandmv has no CPU fallback";
@@ -348,6 +368,7 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     hmv_engine *h = new hmv_engine();
     h->cfg = *cfg;
     h->paper = paper;
+    h->hrnet = hrnet;
     h->fdim = 0;
     for (int i = 0; i < cfg->n_levels; ++i) h->fdim += cfg->channels[i] / 2;
     h->d = h->fdim + ((cfg->pos_enc & HMV_POS2D) ? 2 : 0) + ((cfg->pos_enc & HMV_POS_CROP) ? 10 : 0);
@@ -379,6 +400,91 @@ int hmv_finalize_weights(hmv_handle h) {
     const int exp = h->paper ? 4 : 1;
     const bool h16 = c.dtype == HMV_F16;   // conv stack in fp16; heat-map logits, tokens, fusion, decoder stay fp32
 
+    if (h->hrnet) {
+        // ---- HighResolutionNet: hrnet.py:231-311.  Branch widths 40 / 80 are stored with padded strides 64 / 96.
+        HrNet &hr = h->hr;
+        hr = HrNet();
+        for (int i = 0; i < 4; ++i) hr.ch[i] = kHrChannels[c.backbone - HMV_HRNET_W40][i];
+        L.conv(hr.conv1, "stem.conv1", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 3, 3, /*cin_pad=*/4);
+        L.conv(hr.conv2, "stem.conv2", "backbone.conv2.weight", "", "backbone.bn2", 64, 64, 3, 3);
+        int inpl_ = 64;
+        for (int bi = 0; bi < 4; ++bi) {
+            Block b;
+            const std::string p = "backbone.layer1." + std::to_string(bi), lab = "layer1." + std::to_string(bi);
+            L.conv(b.c1, lab + ".conv1", p + ".conv1.weight", "", p + ".bn1", 64, inpl_, 1, 1);
+            L.conv(b.c2, lab + ".conv2", p + ".conv2.weight", "", p + ".bn2", 64, 64, 3, 3);
+            L.conv(b.c3, lab + ".conv3", p + ".conv3.weight", "", p + ".bn3", 256, 64, 1, 1);
+            b.has_ds = bi == 0;
+            if (b.has_ds) L.conv(b.ds, lab + ".downsample", p + ".downsample.0.weight", "", p + ".downsample.1", 256, 64, 1, 1);
+            inpl_ = 256;
+            hr.layer1.push_back(b);
+        }
+        static const int NMOD[3] = {1, 4, 3};
+        int npre = 1, prec[4] = {256, 0, 0, 0};
+        for (int st = 0; st < 3; ++st) {
+            const int nbr = st + 2;
+            const std::string tp = "backbone.transition" + std::to_string(st + 1);
+            for (int i = 0; i < nbr; ++i) {   // _make_transition_layer: hrnet.py:287-311
+                hr.trans[st][i].clear();
+                if (i < npre) {
+                    if (hr.ch[i] != prec[i]) {
+                        Layer l;
+                        const std::string q = tp + "." + std::to_string(i);
+                        L.conv(l, "transition" + std::to_string(st + 1) + "." + std::to_string(i), q + ".0.weight", "", q + ".1",
+                               hr.ch[i], prec[i], 3, 3, cpad(prec[i]));
+                        hr.trans[st][i].push_back(l);
+                    }
+                } else {
+                    int cin = prec[npre - 1];
+                    for (int j = 0; j < i + 1 - npre; ++j) {
+                        const int outc = (j == i - npre) ? hr.ch[i] : cin;
+                        Layer l;
+                        const std::string q = tp + "." + std::to_string(i) + "." + std::to_string(j);
+                        L.conv(l, "transition" + std::to_string(st + 1) + "." + std::to_string(i) + "." + std::to_string(j),
+                               q + ".0.weight", "", q + ".1", outc, cin, 3, 3, cpad(cin));
+                        hr.trans[st][i].push_back(l);
+                        cin = outc;
+                    }
+                }
+            }
+            hr.stage[st].clear();
+            for (int m = 0; m < NMOD[st]; ++m) {
+                hr.stage[st].emplace_back();
+                HrModule &M = hr.stage[st].back();
+                const std::string mp = "backbone.stage" + std::to_string(st + 2) + "." + std::to_string(m);
+                const std::string ml = "stage" + std::to_string(st + 2) + "." + std::to_string(m);
+                for (int b = 0; b < nbr; ++b)
+                    for (int blk = 0; blk < 4; ++blk) {
+                        const std::string bp = mp + ".branches." + std::to_string(b) + "." + std::to_string(blk);
+                        const std::string bl = ml + ".b" + std::to_string(b) + "." + std::to_string(blk);
+                        L.conv(M.br[b][blk][0], bl + ".conv1", bp + ".conv1.weight", "", bp + ".bn1", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]));
+                        L.conv(M.br[b][blk][1], bl + ".conv2", bp + ".conv2.weight", "", bp + ".bn2", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]));
+                    }
+                for (int i = 0; i < nbr; ++i)
+                    for (int j = 0; j < nbr; ++j) {
+                        const std::string fp = mp + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j);
+                        const std::string fl = ml + ".fuse" + std::to_string(i) + std::to_string(j);
+                        if (j > i) {
+                            Layer l;
+                            L.conv(l, fl, fp + ".0.weight", "", fp + ".1", hr.ch[i], hr.ch[j], 1, 1, cpad(hr.ch[j]));
+                            M.fuse[i][j].push_back(l);
+                        } else if (j < i) {
+                            for (int q = 0; q < i - j; ++q) {
+                                const int outc = (q == i - j - 1) ? hr.ch[i] : hr.ch[j];
+                                Layer l;
+                                const std::string fq = fp + "." + std::to_string(q);
+                                L.conv(l, fl + "." + std::to_string(q), fq + ".0.weight", "", fq + ".1", outc, hr.ch[j], 3, 3, cpad(hr.ch[j]));
+                                M.fuse[i][j].push_back(l);
+                            }
+                        }
+                    }
+            }
+            npre = nbr;
+            for (int i = 0; i < nbr; ++i) prec[i] = hr.ch[i];
+        }
+        // pose_net = nn.Conv2d(C0, 21, 3, stride 2, padding 1): handmvnet.py:51-57
+        L.conv(h->pose0, "pose_net", "pose_net.weight", "pose_net.bias", "", NJ, c.channels[0], 3, 3, cpad(c.channels[0]));
+    } else {
     // ---- backbone: resnet.py:162-177, 189-203
     L.conv(h->stem, "stem", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 7, 7, /*cin_pad=*/h16 ? 8 : 4, h16);
     int inpl = 64;
@@ -436,11 +542,12 @@ int hmv_finalize_weights(hmv_handle h) {
         L.conv(h->pose1, "pose_net.3", "pose_net.3.weight", "pose_net.3.bias", "pose_net.4", 64, 128, 3, 3, 0, h16);
         L.conv(h->pose2, "pose_net.6", "pose_net.6.weight", "pose_net.6.bias", "", NJ, 64, 3, 3, 0, h16);
     }
+    }   // resnet backbones
     // ---- sample nets: nets.py:24-31
     for (int i = 0; i < c.n_levels; ++i) {
         const std::string p = "sample_nets." + std::to_string(i) + ".conv";
         L.conv(h->sample[i], "sample_nets." + std::to_string(i), p + ".0.weight", p + ".0.bias", p + ".1", c.channels[i] / 2,
-               c.channels[i], 1, 1, 0, h16);
+               c.channels[i], 1, 1, h->hrnet ? cpad(c.channels[i]) : 0, h16);
     }
     // ---- fusion: layers.py:177-200
     const int d = h->d;
@@ -613,7 +720,7 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
         }
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
-    for (float *ptr : {din, dout, dw, db, dres}) if (ptr) hipFree(ptr);
+    for (float *ptr : {din, dout, dw, db, dres}) if (ptr) (void)hipFree(ptr);
     if (e != hipSuccess) { g_create_err = std::string("hmv_bench_conv: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
     return HMV_OK;
 }
@@ -640,7 +747,7 @@ struct Runner {
     // One conv / GEMM launch.  in: NHWC [N][H][W][L.Cin] ; returns output dims through Ho/Wo.
     void conv(const Layer &L, const float *in, int N, int H, int W, int stride, int pad_h, int pad_w, float *out, int ldc,
               const float *res, int ldr, int act, int Ho, int Wo, int rg_out = 0, int rg_in = 0, int scatter = 0, int ooy = 0,
-              int oox = 0, bool out_f16 = false) {
+              int oox = 0, bool out_f16 = false, int up = 0, bool fill = false) {
         if (dry || rc != HMV_OK) return;
         ConvParams p{};
         p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res; p.out = out;
@@ -653,6 +760,7 @@ struct Runner {
         p.ldc = ldc; p.ldr = ldr; p.act = act;
         p.rg_out = rg_out; p.rg_in = rg_in;
         p.scatter = scatter; p.osy = scatter ? 2 : 1; p.osx = scatter ? 2 : 1; p.ooy = ooy; p.oox = oox;
+        p.up = up; p.fill = fill ? 1 : 0;
         const ConvTile tile = conv_pick_tile(p.M, p.Cout, p.K);
         ProfRec *pr = nullptr;
         if (h->profiling) {
@@ -693,6 +801,150 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
 #define ACT(n) ((h16) ? ((size_t)(n) + 1) / 2 : (size_t)(n))
 #define LAUNCH(expr) do { if (!dry && R.rc == HMV_OK) R.check((expr), #expr); } while (0)
 
+    // sampled feature levels in the reference's feats[] order (handmvnet.py:165-177), channels-last with row stride ld
+    float *lvl[4] = {nullptr, nullptr, nullptr, nullptr};
+    int lvc[4] = {0, 0, 0, 0}, lvld[4] = {0, 0, 0, 0}, lvh[4] = {0, 0, 0, 0}, lvw[4] = {0, 0, 0, 0}, nkeep = 0;
+    int hmh = 0, hmw = 0;
+    float *hm = nullptr;
+    if (h->hrnet) {
+        // ================= HighResolutionNet.forward (hrnet.py:357-393) =================
+        const HrNet &hr = h->hr;
+        float *in4 = R.alloc((size_t)N * H * W * 4);
+        LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
+        const int H1 = (H + 2 - 3) / 2 + 1, W1 = (W + 2 - 3) / 2 + 1, H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
+        float *c1 = R.alloc((size_t)N * H1 * W1 * 64);
+        R.conv(hr.conv1, in4, N, H, W, 2, 1, 1, c1, 64, nullptr, 0, ACT_RELU, H1, W1);
+        R.release(in4);
+        float *cur = R.alloc((size_t)N * H2 * W2 * 64);
+        R.conv(hr.conv2, c1, N, H1, W1, 2, 1, 1, cur, 64, nullptr, 0, ACT_RELU, H2, W2);
+        R.release(c1);
+        for (const Block &b : hr.layer1) {   // 4 Bottlenecks, planes 64 -> 256 channels
+            float *t1 = R.alloc((size_t)N * H2 * W2 * 64);
+            R.conv(b.c1, cur, N, H2, W2, 1, 0, 0, t1, 64, nullptr, 0, ACT_RELU, H2, W2);
+            float *t2 = R.alloc((size_t)N * H2 * W2 * 64);
+            R.conv(b.c2, t1, N, H2, W2, 1, 1, 1, t2, 64, nullptr, 0, ACT_RELU, H2, W2);
+            R.release(t1);
+            const float *res = cur;
+            float *dsb = nullptr;
+            if (b.has_ds) {
+                dsb = R.alloc((size_t)N * H2 * W2 * 256);
+                R.conv(b.ds, cur, N, H2, W2, 1, 0, 0, dsb, 256, nullptr, 0, ACT_NONE, H2, W2);
+                res = dsb;
+            }
+            float *y = R.alloc((size_t)N * H2 * W2 * 256);
+            R.conv(b.c3, t2, N, H2, W2, 1, 0, 0, y, 256, res, 256, ACT_RELU, H2, W2);
+            R.release(t2);
+            R.release(dsb);
+            R.release(cur);
+            cur = y;
+        }
+        float *xs[4] = {nullptr, nullptr, nullptr, nullptr}, *pre[4] = {cur, nullptr, nullptr, nullptr};
+        int hs[4] = {0, 0, 0, 0}, ws[4] = {0, 0, 0, 0}, prec[4] = {256, 0, 0, 0}, preh[4] = {H2, 0, 0, 0}, prew[4] = {W2, 0, 0, 0};
+        int npre = 1;
+        for (int st = 0; st < 3; ++st) {
+            const int nbr = st + 2;
+            bool moved[4] = {false, false, false, false};
+            for (int i = 0; i < nbr; ++i) {   // transition layers (hrnet.py:287-311, 368-390)
+                const int cp = cpad(hr.ch[i]);
+                if (i < npre) {
+                    hs[i] = preh[i]; ws[i] = prew[i];
+                    if (!hr.trans[st][i].empty()) {
+                        xs[i] = R.alloc((size_t)N * hs[i] * ws[i] * cp);
+                        R.conv(hr.trans[st][i][0], pre[i], N, preh[i], prew[i], 1, 1, 1, xs[i], cp, nullptr, 0, ACT_RELU, hs[i], ws[i],
+                               0, 0, 0, 0, 0, false, 0, /*fill=*/true);
+                    } else {
+                        xs[i] = pre[i];   // x_list.append(y_list[i]): the same tensor
+                        moved[i] = true;
+                    }
+                } else {   // a new, lower-resolution branch from the LAST previous branch
+                    const float *src = pre[npre - 1];
+                    float *tmp = nullptr;
+                    int hh_ = preh[npre - 1], ww_ = prew[npre - 1];
+                    for (const Layer &l : hr.trans[st][i]) {
+                        const int ho = (hh_ + 2 - 3) / 2 + 1, wo = (ww_ + 2 - 3) / 2 + 1, cpo = cpad(l.Cout);
+                        float *o = R.alloc((size_t)N * ho * wo * cpo);
+                        R.conv(l, src, N, hh_, ww_, 2, 1, 1, o, cpo, nullptr, 0, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, false, 0, true);
+                        R.release(tmp);
+                        tmp = o; src = o; hh_ = ho; ww_ = wo;
+                    }
+                    xs[i] = tmp; hs[i] = hh_; ws[i] = ww_;
+                }
+            }
+            for (int i = 0; i < npre; ++i)
+                if (!moved[i]) R.release(pre[i]);
+            for (const HrModule &M : hr.stage[st]) {   // HighResolutionModule.forward (hrnet.py:194-212)
+                for (int b = 0; b < nbr; ++b) {
+                    const int cp = cpad(hr.ch[b]);
+                    for (int blk = 0; blk < 4; ++blk) {
+                        float *t = R.alloc((size_t)N * hs[b] * ws[b] * cp);
+                        R.conv(M.br[b][blk][0], xs[b], N, hs[b], ws[b], 1, 1, 1, t, cp, nullptr, 0, ACT_RELU, hs[b], ws[b], 0, 0, 0, 0, 0,
+                               false, 0, true);
+                        float *y = R.alloc((size_t)N * hs[b] * ws[b] * cp);
+                        R.conv(M.br[b][blk][1], t, N, hs[b], ws[b], 1, 1, 1, y, cp, xs[b], cp, ACT_RELU, hs[b], ws[b], 0, 0, 0, 0, 0, false,
+                               0, true);
+                        R.release(t);
+                        R.release(xs[b]);
+                        xs[b] = y;
+                    }
+                }
+                // fuse: y_i = relu(sum_j f_ij(x_j)).  Every non-identity term is a conv at branch i's resolution whose
+                // epilogue adds the running sum (the identity term x_i rides along as the first residual); the
+                // "1x1 conv + BN + nearest upsample" terms run the 1x1 conv on the up-sampled index map instead.
+                float *outs[4] = {nullptr, nullptr, nullptr, nullptr};
+                for (int i = 0; i < nbr; ++i) {
+                    const int cpi = cpad(hr.ch[i]);
+                    float *running = nullptr;
+                    int nterm = 0;
+                    for (int j = 0; j < nbr; ++j) {
+                        if (j == i) continue;
+                        const bool first = nterm == 0, last = nterm == nbr - 2;
+                        const float *res = first ? xs[i] : running;
+                        const int act = last ? ACT_RELU : ACT_NONE;
+                        float *o = R.alloc((size_t)N * hs[i] * ws[i] * cpi);
+                        if (j > i) {
+                            R.conv(M.fuse[i][j][0], xs[j], N, hs[j], ws[j], 1, 0, 0, o, cpi, res, cpi, act, hs[i], ws[i], 0, 0, 0, 0, 0,
+                                   false, /*up=*/j - i, true);
+                        } else {
+                            const float *src = xs[j];
+                            float *tmp = nullptr;
+                            int hh_ = hs[j], ww_ = ws[j];
+                            const int nq = i - j;
+                            for (int q = 0; q < nq; ++q) {
+                                const Layer &l = M.fuse[i][j][q];
+                                const int ho = (hh_ + 2 - 3) / 2 + 1, wo = (ww_ + 2 - 3) / 2 + 1;
+                                if (q == nq - 1) {
+                                    R.conv(l, src, N, hh_, ww_, 2, 1, 1, o, cpi, res, cpi, act, ho, wo, 0, 0, 0, 0, 0, false, 0, true);
+                                } else {
+                                    const int cpo = cpad(l.Cout);
+                                    float *t = R.alloc((size_t)N * ho * wo * cpo);
+                                    R.conv(l, src, N, hh_, ww_, 2, 1, 1, t, cpo, nullptr, 0, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, false, 0, true);
+                                    R.release(tmp);
+                                    tmp = t; src = t;
+                                }
+                                hh_ = ho; ww_ = wo;
+                            }
+                            R.release(tmp);
+                        }
+                        if (!first) R.release(running);
+                        running = o;
+                        ++nterm;
+                    }
+                    outs[i] = running;
+                }
+                for (int b = 0; b < nbr; ++b) { R.release(xs[b]); xs[b] = outs[b]; }
+            }
+            npre = nbr;
+            for (int i = 0; i < nbr; ++i) { pre[i] = xs[i]; prec[i] = hr.ch[i]; preh[i] = hs[i]; prew[i] = ws[i]; xs[i] = nullptr; }
+        }
+        (void)prec;
+        nkeep = 4;
+        for (int i = 0; i < 4; ++i) { lvl[i] = pre[i]; lvc[i] = hr.ch[i]; lvld[i] = cpad(hr.ch[i]); lvh[i] = preh[i]; lvw[i] = prew[i]; }
+        if (h->capture && !dry && h->cap_feat0) LAUNCH(launch_nhwc_to_nchw(lvl[0], h->cap_feat0, N, lvh[0], lvw[0], lvc[0], s, lvld[0]));
+        // pose_net = Conv2d(C0, 21, 3, stride 2, padding 1) on the highest-resolution branch (handmvnet.py:51-57, 180)
+        hmh = (lvh[0] + 2 - 3) / 2 + 1; hmw = (lvw[0] + 2 - 3) / 2 + 1;
+        hm = R.alloc((size_t)N * hmh * hmw * 32);
+        R.conv(h->pose0, lvl[0], N, lvh[0], lvw[0], 2, 1, 1, hm, 32, nullptr, 0, ACT_NONE, hmh, hmw);
+    } else {
     // ---- stem: conv1 7x7 s2 + BN + ReLU, maxpool 3x3 s2 (resnet.py:218-221)
     float *in4 = R.alloc((size_t)N * H * W * 4);   // NHWC4 fp32 and NHWC8 fp16 are both 16 bytes per pixel
     if (h16) LAUNCH(launch_nchw_to_nhwc8_f16(x, in4, N, H, W, s));
@@ -770,8 +1022,6 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     }
 
     // ---- pose_net (handmvnet.py:70-86, 180) -> channels-last heat map with row stride 32
-    int hmh, hmw;
-    float *hm;
     if (h->paper) {
         hmh = fh; hmw = fw;
         float *ph = R.alloc(ACT((size_t)N * fh * fw * 512));
@@ -793,6 +1043,13 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         R.conv(h->pose2, p1, N, hmh, hmw, 1, 1, 1, hm, 32, nullptr, 0, ACT_NONE, hmh, hmw);
         R.release(p1);
     }
+    for (int i = 0; i < 3; ++i) {   // feats = [layer3, layer2, layer1]; only the kept levels are non-null
+        const int li = 2 - i;
+        if (!level[li]) continue;
+        lvl[nkeep] = level[li]; lvc[nkeep] = lc[li]; lvld[nkeep] = lc[li]; lvh[nkeep] = lh[li]; lvw[nkeep] = lw[li];
+        ++nkeep;
+    }
+    }   // resnet backbones
     // ---- soft-argmax (handmvnet.py:182, 252)
     float *coords = R.alloc((size_t)N * NJ * 2);
     LAUNCH(launch_soft_argmax(hm, 32, N, hmh, hmw, coords, crop_img, (float)c.image_size, (float)c.heatmap_size, heatmap, s));
@@ -804,17 +1061,17 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     float *tokens = R.alloc((size_t)N * NJ * ldt);
     int col0 = 0;
     for (int i = 0; i < c.n_levels; ++i) {
-        const int li = 2 - i, Ci = lc[li], co = Ci / 2;
+        const int Ci = lvld[i], co = lvc[i] / 2;   // gather the (padded) channel rows; the conv's pad weights are zero
         float *g = R.alloc(ACT((size_t)N * NJ * 4 * Ci));
-        LAUNCH(launch_sample_gather(level[li], N, lh[li], lw[li], Ci, coords, g, s, h16 ? 2 : 4));
+        LAUNCH(launch_sample_gather(lvl[i], N, lvh[i], lvw[i], Ci, coords, g, s, h16 ? 2 : 4));
         float *s4 = R.alloc((size_t)N * NJ * 4 * co);
         R.gemm(h->sample[i], g, N * NJ * 4, s4, co, nullptr, 0, ACT_RELU);
         R.release(g);
-        LAUNCH(launch_sample_blend(s4, co, co, N, lh[li], lw[li], coords, tokens, ldt, col0, s));
+        LAUNCH(launch_sample_blend(s4, co, co, N, lvh[i], lvw[i], coords, tokens, ldt, col0, s));
         R.release(s4);
         col0 += co;
     }
-    for (int li = 0; li < 3; ++li) R.release(level[li]);
+    for (int i = 0; i < nkeep; ++i) R.release(lvl[i]);
     // pos2d / FoV / zero pad / PE (handmvnet.py:189-225; fusion.py:27-28)
     LAUNCH(launch_tokens_finalize(tokens, ldt, d, h->fdim, N, V, coords, bbox, intr, c.pos_enc, h->pe,
                                   (h->capture && h->cap_tokens) ? h->cap_tokens : nullptr, s));
@@ -888,7 +1145,7 @@ int ensure_capture(hmv_engine *h, int B) {
     if (!h->capture || h->cap_batch >= B) return HMV_OK;
     const hmv_config &c = h->cfg;
     const int N = B * c.num_views;
-    const int fdiv = h->paper ? 8 : 16;
+    const int fdiv = h->hrnet ? 4 : (h->paper ? 8 : 16);
     for (float **p : {&h->cap_feat0, &h->cap_coords, &h->cap_tokens, &h->cap_fused}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;

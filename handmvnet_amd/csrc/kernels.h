@@ -19,6 +19,9 @@ struct ConvParams {
     const void *res;    // residual, row-major [M'][ldr] or null; fp16 if res_f16
     void *out;          // [M''][ldc]; fp16 if out_f16
     int in_f16, res_f16, out_f16;
+    int up;             // 1x1 mode only: output pixel (ho, wo) reads input pixel (ho >> up, wo >> up) -- a 1x1 conv
+                        // commutes with nearest-neighbour upsampling (HRNet fuse layers); H, W are the INPUT dims
+    int fill;           // write columns [Cout, ldc) too (exact zeros): keeps padded channel strides clean
     int N, H, W, Cin;
     int Ho, Wo, Cout;
     int R, S, stride, pad_h, pad_w;
@@ -75,7 +78,7 @@ hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, in
 hipError_t launch_cheb_mix(const float *y, int ldy, int B, int co, const float *tk, const float *bias, int leaky,
                            float *out, int ldo, hipStream_t s);
 // NHWC -> NCHW copy (stage capture)
-hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t s, int ld = 0);
 hipError_t launch_copy_rows(const float *in, int ldi, float *out, int ldo, int rows, int cols, hipStream_t s);
 
 }  // namespace hmv

@@ -513,7 +513,7 @@ hipError_t launch_cheb_mix(const float *y, int ldy, int B, int co, const float *
 }
 
 // ------------------------------------------------------------------ capture helpers
-__global__ void nhwc_to_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, int HW, int C, size_t total) {
+__global__ void nhwc_to_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, int HW, int C, int ld, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {  // i indexes the NCHW output
@@ -521,7 +521,7 @@ __global__ void nhwc_to_nchw_kernel(const float *__restrict__ in, float *__restr
         const size_t t = i / HW;
         const int c = (int)(t % C);
         const size_t n = t / C;
-        out[i] = in[(n * HW + p) * C + c];
+        out[i] = in[(n * HW + p) * ld + c];
     }
 }
 __global__ void nhwc_f16_to_nchw_kernel(const _Float16 *__restrict__ in, float *__restrict__ out, int HW, int C, size_t total) {
@@ -541,10 +541,10 @@ hipError_t launch_nhwc_f16_to_nchw(const void *in, float *out, int N, int H, int
     hipLaunchKernelGGL(nhwc_f16_to_nchw_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const _Float16 *>(in), out, H * W, C, total);
     return hipGetLastError();
 }
-hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t s) {
+hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t s, int ld) {
     const size_t total = (size_t)N * H * W * C;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid), dim3(256), 0, s, in, out, H * W, C, total);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid), dim3(256), 0, s, in, out, H * W, C, ld ? ld : C, total);
     return hipGetLastError();
 }
 

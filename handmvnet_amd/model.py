@@ -32,7 +32,7 @@ class HandMvNet(torch.nn.Module):
         super().__init__()
         self.train_params, self.model_params, self.data_params = train_params, model_params, data_params
         self.cfg: HotPathConfig = config_from_params(train_params, model_params, data_params)
-        if self.cfg.backbone_type != "50_paper" and self.cfg.early_return != 3:
+        if self.cfg.backbone_type in ("18", "34") and self.cfg.early_return != 3:
             raise NotImplementedError("ResNet-18/34 are supported with backbone_early_return=3 (every release config)")
         self.debug = train_params["debug"]
         self.num_views = self.cfg.num_views
@@ -202,7 +202,7 @@ class HandMvNet(torch.nn.Module):
         hh, ww, idx, batch, dt = self._last_key
         h = self._engines[(hh, ww, idx, dt)]
         n, d, cfg = batch * self.num_views, self.feat_dim, self.cfg
-        fdiv = 8 if cfg.is_paper else 16
+        fdiv = 4 if cfg.is_hrnet else (8 if cfg.is_paper else 16)
         shape = {"feat0": (n, cfg.backbone_channels[0], hh // fdiv, ww // fdiv), "coords_hm": (n, 21, 2),
                  "tokens": (batch, self.num_views * 21, d), "fused": (batch, 21, d)}[name]
         out = torch.empty(shape, device=f"cuda:{idx}", dtype=torch.float32)

@@ -16,7 +16,8 @@ from dataclasses import dataclass, field
 from typing import Dict, List, Sequence, Tuple
 
 POS2D, CROP, SIN = 1, 2, 4
-BACKBONE_IDS = {"18": 0, "34": 1, "50_paper": 2}
+BACKBONE_IDS = {"18": 0, "34": 1, "50_paper": 2, "w40": 3, "w64": 4}
+HRNET_CHANNELS = {"w40": [40, 80, 160, 320], "w64": [64, 128, 256, 512]}   # hrnet.py:430-447
 RESNET_BLOCKS = {"18": [2, 2, 2, 2], "34": [3, 4, 6, 3], "50_paper": [3, 4, 6, 3]}
 N_JOINTS = 21
 N_HEADS = 8
@@ -56,6 +57,10 @@ class HotPathConfig:
     def is_paper(self) -> bool:
         return "paper" in self.backbone_type
 
+    @property
+    def is_hrnet(self) -> bool:
+        return self.backbone_type in HRNET_CHANNELS
+
 
 def config_from_params(train_params: dict, model_params: dict, data_params: dict) -> HotPathConfig:
     """Validate the three reference dicts exactly where the reference does
@@ -68,9 +73,12 @@ def config_from_params(train_params: dict, model_params: dict, data_params: dict
     backbone = model_params.get("backbone", "hrnet")
     assert backbone in ["hrnet", "resnet"], "Backbone should be one of ['hrnet', 'resnet']"
     if backbone == "hrnet":
-        raise NotImplementedError("hrnet backbone is SURVEY.md section 8(f) 'next', not built yet")
-    btype = model_params.get("backbone_type", "34")
-    assert btype in ["18", "34", "50_paper"], "Supports only 18, 34, 50_paper"
+        btype = model_params.get("backbone_type", "w40")   # handmvnet.py:42
+        if btype not in HRNET_CHANNELS:                     # hrnet.py:449
+            raise Exception("HRNet only supports ['w64', 'w40'] as model_type, found: " + str(btype))
+    else:
+        btype = model_params.get("backbone_type", "34")
+        assert btype in ["18", "34", "50_paper"], "Supports only 18, 34, 50_paper"
     if model_params["fusion"] != "cross_attn":
         if model_params["fusion"] == "cross_attn_learnable_query":
             raise NotImplementedError("cross_attn_learnable_query is SURVEY.md section 8(f) 'next'")
@@ -95,7 +103,7 @@ def config_from_params(train_params: dict, model_params: dict, data_params: dict
         fusion_layers=int(layers),
         use_gcn=bool(model_params["use_gcn"]),
         # ResNet50_Paper hard-codes freeze_batchnorm=False (resnet.py:354)
-        freeze_bn=bool(model_params.get("freeze_bn", False)) and btype != "50_paper",
+        freeze_bn=bool(model_params.get("freeze_bn", False)) and btype in ("18", "34"),
         early_return=int(model_params.get("backbone_early_return", 3)),
     )
 
@@ -113,6 +121,10 @@ def state_dict_layout(cfg: HotPathConfig) -> "OrderedDict[str, tuple]":
     """Key -> shape, in the reference's module registration order.  Includes the
     never-executed layer4 / fc parameters r18/r34 checkpoints carry."""
     k: "OrderedDict[str, tuple]" = OrderedDict()
+    if cfg.is_hrnet:
+        _hrnet_layout(k, cfg)
+        _heads_layout(k, cfg)
+        return k
     fz = cfg.freeze_bn
     blocks = RESNET_BLOCKS[cfg.backbone_type]
     bottleneck = cfg.is_paper
@@ -148,8 +160,17 @@ def state_dict_layout(cfg: HotPathConfig) -> "OrderedDict[str, tuple]":
     if not cfg.is_paper:
         k["backbone.fc.weight"] = (1000, 512 * exp)
         k["backbone.fc.bias"] = (1000,)
+    _heads_layout(k, cfg)
+    return k
+
+
+def _heads_layout(k: "OrderedDict[str, tuple]", cfg: HotPathConfig) -> None:
+    """pose_net, sample_nets, fusion and decoder keys (handmvnet.py:46-100)."""
     c0 = cfg.backbone_channels[0]
-    if cfg.is_paper:
+    if cfg.is_hrnet:   # handmvnet.py:51-57: nn.Conv2d(C0, 21, 3, stride 2, padding 1)
+        k["pose_net.weight"] = (21, c0, 3, 3)
+        k["pose_net.bias"] = (21,)
+    elif cfg.is_paper:
         k["pose_net.0.weight"] = (512, c0, 1, 1)
         k["pose_net.0.bias"] = (512,)
         _bn(k, "pose_net.1", 512, False)
@@ -196,7 +217,64 @@ def state_dict_layout(cfg: HotPathConfig) -> "OrderedDict[str, tuple]":
         k["joints_decoder.joints_fc1.bias"] = (64,)
         k["joints_decoder.joints_fc2.weight"] = (3, 64)
         k["joints_decoder.joints_fc2.bias"] = (3,)
-    return k
+
+
+def _hrnet_layout(k: "OrderedDict[str, tuple]", cfg: HotPathConfig) -> None:
+    """HighResolutionNet module tree: backbones/hrnet.py:231-311 (ctor), 152-185 (fuse layers),
+    287-311 (transition layers).  BatchNorm2d everywhere (never frozen)."""
+    ch = HRNET_CHANNELS[cfg.backbone_type]
+    k["backbone.conv1.weight"] = (64, 3, 3, 3)
+    _bn(k, "backbone.bn1", 64, False)
+    k["backbone.conv2.weight"] = (64, 64, 3, 3)
+    _bn(k, "backbone.bn2", 64, False)
+    inpl = 64
+    for bi in range(4):   # stage 1: 4 Bottlenecks, planes 64
+        p = f"backbone.layer1.{bi}"
+        k[p + ".conv1.weight"] = (64, inpl, 1, 1)
+        _bn(k, p + ".bn1", 64, False)
+        k[p + ".conv2.weight"] = (64, 64, 3, 3)
+        _bn(k, p + ".bn2", 64, False)
+        k[p + ".conv3.weight"] = (256, 64, 1, 1)
+        _bn(k, p + ".bn3", 256, False)
+        if bi == 0:
+            k[p + ".downsample.0.weight"] = (256, 64, 1, 1)
+            _bn(k, p + ".downsample.1", 256, False)
+        inpl = 256
+    pre = [256]
+    for st, (nmod, nbr) in enumerate([(1, 2), (4, 3), (3, 4)]):
+        cur = ch[:nbr]
+        tp = f"backbone.transition{st + 1}"
+        for i in range(nbr):   # _make_transition_layer
+            if i < len(pre):
+                if cur[i] != pre[i]:
+                    k[f"{tp}.{i}.0.weight"] = (cur[i], pre[i], 3, 3)
+                    _bn(k, f"{tp}.{i}.1", cur[i], False)
+            else:
+                for j in range(i + 1 - len(pre)):
+                    outc = cur[i] if j == i - len(pre) else pre[-1]
+                    k[f"{tp}.{i}.{j}.0.weight"] = (outc, pre[-1], 3, 3)
+                    _bn(k, f"{tp}.{i}.{j}.1", outc, False)
+        for m in range(nmod):   # HighResolutionModule
+            mp = f"backbone.stage{st + 2}.{m}"
+            for b in range(nbr):
+                for blk in range(4):
+                    bp = f"{mp}.branches.{b}.{blk}"
+                    k[bp + ".conv1.weight"] = (cur[b], cur[b], 3, 3)
+                    _bn(k, bp + ".bn1", cur[b], False)
+                    k[bp + ".conv2.weight"] = (cur[b], cur[b], 3, 3)
+                    _bn(k, bp + ".bn2", cur[b], False)
+            for i in range(nbr):
+                for j in range(nbr):
+                    fp = f"{mp}.fuse_layers.{i}.{j}"
+                    if j > i:
+                        k[fp + ".0.weight"] = (cur[i], cur[j], 1, 1)
+                        _bn(k, fp + ".1", cur[i], False)
+                    elif j < i:
+                        for q in range(i - j):
+                            outc = cur[i] if q == i - j - 1 else cur[j]
+                            k[f"{fp}.{q}.0.weight"] = (outc, cur[j], 3, 3)
+                            _bn(k, f"{fp}.{q}.1", outc, False)
+        pre = cur
 
 
 def executed_keys(cfg: HotPathConfig) -> List[str]:

@@ -63,7 +63,12 @@ def _tensor(key: str, shape: tuple, seed: int, cfg: HotPathConfig) -> np.ndarray
     elif len(shape) == 1 and leaf == "weight":          # BN gamma / LayerNorm weight
         v = 0.5 + uniform01(key, seed, n)
         # last BN of a residual branch: keep the residual stream from growing block by block
-        if key.startswith("backbone.layer") and (
+        if cfg.is_hrnet:
+            if (".layer1." in key and ".bn3." in key) or (".branches." in key and ".bn2." in key):
+                v = v * 0.25
+            elif ".fuse_layers." in key:
+                v = v * 0.5   # up to 4 fuse terms are summed per branch
+        elif key.startswith("backbone.layer") and (
                 (cfg.is_paper and ".bn3." in key) or (not cfg.is_paper and ".bn2." in key)):
             v = v * 0.25
     elif leaf == "bias":
@@ -76,7 +81,7 @@ def _tensor(key: str, shape: tuple, seed: int, cfg: HotPathConfig) -> np.ndarray
         else:
             fan_in = shape[1] * shape[2] * shape[3]
         gain = 2.0
-        last_hm = "pose_net.3.weight" if cfg.is_paper else "pose_net.6.weight"
+        last_hm = "pose_net.weight" if cfg.is_hrnet else ("pose_net.3.weight" if cfg.is_paper else "pose_net.6.weight")
         if key == last_hm:
             # heat-map std ~0.03 -> x1000 temperature gives logits of std ~30: mostly one-hot
             # joints with a healthy tail of genuinely soft (sub-pixel) ones

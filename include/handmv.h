@@ -29,8 +29,9 @@ typedef struct hmv_engine *hmv_handle;
 enum { HMV_OK = 0, HMV_ERR_ARG = 1, HMV_ERR_STATE = 2, HMV_ERR_MISSING_TENSOR = 3, HMV_ERR_SHAPE = 4, HMV_ERR_HIP = 5,
        HMV_ERR_UNSUPPORTED = 6 };
 
-/* model_params["backbone_type"]: "18" | "34" | "50_paper"   (handmvnet.py:60-61) */
-enum { HMV_RESNET18 = 0, HMV_RESNET34 = 1, HMV_RESNET50_PAPER = 2 };
+/* model_params["backbone"] = "resnet": backbone_type "18" | "34" | "50_paper"   (handmvnet.py:59-68)
+ * model_params["backbone"] = "hrnet":  backbone_type "w40" | "w64"            (handmvnet.py:41-57, hrnet.py:430-447) */
+enum { HMV_RESNET18 = 0, HMV_RESNET34 = 1, HMV_RESNET50_PAPER = 2, HMV_HRNET_W40 = 3, HMV_HRNET_W64 = 4 };
 /* model_params["pos_enc"] subset of {pos2d, crop, sin}       (handmvnet.py:89-95) */
 enum { HMV_POS2D = 1, HMV_POS_CROP = 2, HMV_POS_SIN = 4 };
 /* model_params["use_gcn"]: JointsDecoderNN | JointsDecoderGCN (handmvnet.py:152-155) */
@@ -41,9 +42,9 @@ enum { HMV_F32 = 0, HMV_F16 = 1 };
 
 typedef struct hmv_config {
     int32_t struct_size;   /* sizeof(hmv_config), ABI guard */
-    int32_t backbone;      /* HMV_RESNET* */
+    int32_t backbone;      /* HMV_RESNET* | HMV_HRNET_* */
     int32_t n_levels;      /* len(model_params["backbone_channels"]) */
-    int32_t channels[4];   /* model_params["backbone_channels"], last backbone level first */
+    int32_t channels[4];   /* model_params["backbone_channels"] (ResNet: last level first; HRNet: highest resolution first) */
     int32_t num_views;     /* model_params["num_views"] */
     int32_t height, width; /* frame size the plan is built for (x.shape[-2:]) */
     int32_t image_size;    /* data_params["image_size"]   -- config constant, handmvnet.py:252 */

@@ -357,6 +357,154 @@ static float *res_block(float *x, int N, int *C, int *H, int *W, const char *pre
     return o3;
 }
 
+/* ------------------------------------------------------------------ HRNet (backbones/hrnet.py) */
+/* conv (no bias) + BatchNorm2d (+ReLU): the building block of every HRNet Sequential */
+static float *conv_bn(const float *x, int N, int Cin, int H, int W, const char *wkey, const char *bnprefix, int Cout,
+                      int k, int stride, int pad, int relu, int *Ho, int *Wo) {
+    int ho = (H + 2 * pad - k) / stride + 1, wo = (W + 2 * pad - k) / stride + 1;
+    float *o = falloc((size_t)N * Cout * ho * wo);
+    conv2d(x, N, Cin, H, W, T("%s", wkey)->data, NULL, Cout, k, k, stride, pad, o, &ho, &wo);
+    bn_eval(o, N, Cout, ho * wo, bnprefix, relu);
+    *Ho = ho;
+    *Wo = wo;
+    return o;
+}
+
+/* nn.Upsample(scale_factor=2**s, mode='nearest'): hrnet.py:165 */
+static float *upsample_nearest(const float *x, int NC, int H, int W, int s) {
+    int f = 1 << s, Ho = H * f, Wo = W * f;
+    float *o = falloc((size_t)NC * Ho * Wo);
+#pragma omp parallel for
+    for (int i = 0; i < NC; ++i)
+        for (int y = 0; y < Ho; ++y)
+            for (int xx = 0; xx < Wo; ++xx) o[((size_t)i * Ho + y) * Wo + xx] = x[((size_t)i * H + (y >> s)) * W + (xx >> s)];
+    return o;
+}
+
+/* HighResolutionModule.forward: hrnet.py:194-212.  x[] (nbr branches) is consumed and replaced. */
+static void hr_module(float **x, const int *ch, int *h, int *w, int nbr, int N, const char *mp) {
+    char key[192], bnk[192];
+    for (int b = 0; b < nbr; ++b)
+        for (int blk = 0; blk < 4; ++blk) { /* _make_one_branch: 4 BasicBlocks, no downsample */
+            int C = ch[b], hh = h[b], ww = w[b];
+            snprintf(key, sizeof key, "%s.branches.%d.%d", mp, b, blk);
+            float *nx = res_block(x[b], N, &C, &hh, &ww, key, ch[b], 1, 0);
+            free(x[b]);
+            x[b] = nx;
+        }
+    float *out[4];
+    for (int i = 0; i < nbr; ++i) {
+        float *y = NULL;
+        size_t tot = (size_t)N * ch[i] * h[i] * w[i];
+        for (int j = 0; j < nbr; ++j) {
+            float *term;
+            int owned = 1;
+            if (j == i) {
+                term = x[j];
+                owned = 0;
+            } else if (j > i) { /* 1x1 conv + BN + nearest upsample */
+                int ho, wo;
+                snprintf(key, sizeof key, "%s.fuse_layers.%d.%d.0.weight", mp, i, j);
+                snprintf(bnk, sizeof bnk, "%s.fuse_layers.%d.%d.1", mp, i, j);
+                float *c = conv_bn(x[j], N, ch[j], h[j], w[j], key, bnk, ch[i], 1, 1, 0, 0, &ho, &wo);
+                term = upsample_nearest(c, N * ch[i], ho, wo, j - i);
+                free(c);
+            } else { /* i - j stride-2 3x3 convs; ReLU on all but the last */
+                const float *cur = x[j];
+                float *tmp = NULL;
+                int hc = h[j], wc = w[j];
+                for (int q = 0; q < i - j; ++q) {
+                    int last = q == i - j - 1, outc = last ? ch[i] : ch[j];
+                    snprintf(key, sizeof key, "%s.fuse_layers.%d.%d.%d.0.weight", mp, i, j, q);
+                    snprintf(bnk, sizeof bnk, "%s.fuse_layers.%d.%d.%d.1", mp, i, j, q);
+                    float *nx = conv_bn(cur, N, ch[j], hc, wc, key, bnk, outc, 3, 2, 1, !last, &hc, &wc);
+                    free(tmp);
+                    tmp = nx;
+                    cur = nx;
+                }
+                term = tmp;
+            }
+            if (!y) { /* y = x[0] if i == 0 else fuse_layers[i][0](x[0]) */
+                y = falloc(tot);
+                memcpy(y, term, tot * sizeof(float));
+            } else {
+                for (size_t e = 0; e < tot; ++e) y[e] = y[e] + term[e];
+            }
+            if (owned) free(term);
+        }
+        relu_(y, tot);
+        out[i] = y;
+    }
+    for (int b = 0; b < nbr; ++b) { free(x[b]); x[b] = out[b]; }
+}
+
+/* HighResolutionNet.forward: hrnet.py:357-393.  Returns 4 feature maps (highest resolution first). */
+static void hrnet_forward(int w64, const float *x, int N, int H, int W, float **feats, int *fc, int *fh, int *fw) {
+    static const int CH[2][4] = {{40, 80, 160, 320}, {64, 128, 256, 512}};
+    const int *ch = CH[w64];
+    int h1, w1, h2, w2;
+    char key[192], bnk[192];
+    float *c1 = conv_bn(x, N, 3, H, W, "backbone.conv1.weight", "backbone.bn1", 64, 3, 2, 1, 1, &h1, &w1);
+    float *cur = conv_bn(c1, N, 64, h1, w1, "backbone.conv2.weight", "backbone.bn2", 64, 3, 2, 1, 1, &h2, &w2);
+    free(c1);
+    int C = 64, hc = h2, wc = w2;
+    for (int bi = 0; bi < 4; ++bi) { /* layer1: 4 Bottlenecks */
+        snprintf(key, sizeof key, "backbone.layer1.%d", bi);
+        float *nx = res_block(cur, N, &C, &hc, &wc, key, 64, 1, 1);
+        free(cur);
+        cur = nx;
+    }
+    float *xs[4] = {0, 0, 0, 0};
+    int hs[4], ws[4];
+    int npre = 1, prec[4] = {256, 0, 0, 0};
+    float *pre[4] = {cur, 0, 0, 0};
+    int preh[4] = {hc, 0, 0, 0}, prew[4] = {wc, 0, 0, 0};
+    static const int NMOD[3] = {1, 4, 3};
+    for (int st = 0; st < 3; ++st) {
+        int nbr = st + 2;
+        for (int i = 0; i < nbr; ++i) { /* transition layers: hrnet.py:287-311, 368-390 */
+            if (i < npre) {
+                if (ch[i] != prec[i]) {
+                    snprintf(key, sizeof key, "backbone.transition%d.%d.0.weight", st + 1, i);
+                    snprintf(bnk, sizeof bnk, "backbone.transition%d.%d.1", st + 1, i);
+                    xs[i] = conv_bn(pre[i], N, prec[i], preh[i], prew[i], key, bnk, ch[i], 3, 1, 1, 1, &hs[i], &ws[i]);
+                } else {
+                    size_t tot = (size_t)N * prec[i] * preh[i] * prew[i];
+                    xs[i] = falloc(tot);
+                    memcpy(xs[i], pre[i], tot * sizeof(float));
+                    hs[i] = preh[i];
+                    ws[i] = prew[i];
+                }
+            } else { /* new branch from the LAST previous branch through (i + 1 - npre) stride-2 convs */
+                const float *src = pre[npre - 1];
+                float *tmp = NULL;
+                int hh = preh[npre - 1], ww = prew[npre - 1], cin = prec[npre - 1];
+                for (int j = 0; j < i + 1 - npre; ++j) {
+                    int outc = (j == i - npre) ? ch[i] : cin;
+                    snprintf(key, sizeof key, "backbone.transition%d.%d.%d.0.weight", st + 1, i, j);
+                    snprintf(bnk, sizeof bnk, "backbone.transition%d.%d.%d.1", st + 1, i, j);
+                    float *nx = conv_bn(src, N, cin, hh, ww, key, bnk, outc, 3, 2, 1, 1, &hh, &ww);
+                    free(tmp);
+                    tmp = nx;
+                    src = nx;
+                    cin = outc;
+                }
+                xs[i] = tmp;
+                hs[i] = hh;
+                ws[i] = ww;
+            }
+        }
+        for (int i = 0; i < npre; ++i) free(pre[i]);
+        for (int m = 0; m < NMOD[st]; ++m) {
+            snprintf(key, sizeof key, "backbone.stage%d.%d", st + 2, m);
+            hr_module(xs, ch, hs, ws, nbr, N, key);
+        }
+        npre = nbr;
+        for (int i = 0; i < nbr; ++i) { pre[i] = xs[i]; prec[i] = ch[i]; preh[i] = hs[i]; prew[i] = ws[i]; xs[i] = NULL; }
+    }
+    for (int i = 0; i < 4; ++i) { feats[i] = pre[i]; fc[i] = ch[i]; fh[i] = preh[i]; fw[i] = prew[i]; }
+}
+
 /* ------------------------------------------------------------------ heads */
 /* soft_argmax_2d(heatmap, temperature=1000): models/utils.py:35-62 */
 static void soft_argmax_2d(const float *hm, int NC, int H, int W, float *coords) {
@@ -583,8 +731,24 @@ int hmvo_forward(const hmvo_config *cfg, int B, int H, int W, const float *x, co
     g_missing = 0;
     g_err[0] = 0;
     static const int blocks[3][4] = {{2, 2, 2, 2}, {3, 4, 6, 3}, {3, 4, 6, 3}};
-    int V = cfg->num_views, N = B * V, paper = cfg->backbone == 2;
+    int V = cfg->num_views, N = B * V, paper = cfg->backbone == 2, hrnet = cfg->backbone >= 3;
     int C, Hc, Wc, h1, w1;
+    const float *feats[4];
+    int fc[4], fh[4], fw[4], nfe;
+    float *lv[4] = {0, 0, 0, 0};
+    float *hm;
+    int hh, hw;
+    if (hrnet) {
+        /* handmvnet.py:46-57: HRNet returns a LIST (highest resolution first); pose_net = Conv2d(C0, 21, 3, 2, 1) */
+        hrnet_forward(cfg->backbone == 4, x, N, H, W, lv, fc, fh, fw);
+        nfe = 4;
+        for (int i = 0; i < 4; ++i) feats[i] = lv[i];
+        if (cfg->n_levels > 4 || fc[0] != cfg->channels[0]) { snprintf(g_err, sizeof g_err, "backbone_channels do not match the backbone"); return 2; }
+        if (feat0_out) memcpy(feat0_out, feats[0], sizeof(float) * (size_t)N * fc[0] * fh[0] * fw[0]);
+        hh = (fh[0] + 2 - 3) / 2 + 1; hw = (fw[0] + 2 - 3) / 2 + 1;
+        hm = falloc((size_t)N * NJ * hh * hw);
+        conv2d(feats[0], N, fc[0], fh[0], fw[0], T("pose_net.weight")->data, T("pose_net.bias")->data, NJ, 3, 3, 2, 1, hm, &hh, &hw);
+    } else {
     /* ---- ResNet.forward: resnet.py:216-254 */
     float *c1 = falloc((size_t)N * 64 * (H / 2 + 1) * (W / 2 + 1));
     conv2d(x, N, 3, H, W, T("backbone.conv1.weight")->data, NULL, 64, 7, 7, 2, 3, c1, &h1, &w1);
@@ -593,7 +757,6 @@ int hmvo_forward(const hmvo_config *cfg, int B, int H, int W, const float *x, co
     maxpool_3s2p1(c1, N, 64, h1, w1, cur, &Hc, &Wc);
     free(c1);
     C = 64;
-    float *lv[3] = {0, 0, 0};
     int lc[3], lh[3], lw[3];
     for (int li = 0; li < 3; ++li) {
         int planes = 64 << li, stride = li == 0 ? 1 : 2;
@@ -610,17 +773,15 @@ int hmvo_forward(const hmvo_config *cfg, int B, int H, int W, const float *x, co
         lv[li] = cur; lc[li] = C; lh[li] = Hc; lw[li] = Wc;
     }
     /* handmvnet.py:165-177: r18/34 -> [layer3, layer2, layer1]; paper -> [layer3] */
-    const float *feats[3];
-    int fc[3], fh[3], fw[3], nfe = paper ? 1 : 3;
-    for (int i = 0; i < nfe; ++i) { feats[i] = lv[2 - i]; fc[i] = lc[2 - i]; fh[i] = lh[2 - i]; fw[i] = lw[2 - i]; }
+    nfe = paper ? 1 : 3;
+    float *lvr[3] = {lv[0], lv[1], lv[2]};
+    for (int i = 0; i < nfe; ++i) { feats[i] = lvr[2 - i]; fc[i] = lc[2 - i]; fh[i] = lh[2 - i]; fw[i] = lw[2 - i]; }
     if (cfg->n_levels > nfe || fc[0] != cfg->channels[0]) {
         snprintf(g_err, sizeof g_err, "backbone_channels do not match the backbone");
         return 2;
     }
     if (feat0_out) memcpy(feat0_out, feats[0], sizeof(float) * (size_t)N * fc[0] * fh[0] * fw[0]);
     /* ---- pose_net: handmvnet.py:70-86,180 */
-    float *hm;
-    int hh, hw;
     if (paper) {
         float *p0 = falloc((size_t)N * 512 * fh[0] * fw[0]);
         conv2d(feats[0], N, fc[0], fh[0], fw[0], T("pose_net.0.weight")->data, T("pose_net.0.bias")->data, 512, 1, 1, 1,
@@ -643,6 +804,7 @@ int hmvo_forward(const hmvo_config *cfg, int B, int H, int W, const float *x, co
         free(p0);
         free(p1);
     }
+    } /* resnet */
     if (heatmap) memcpy(heatmap, hm, sizeof(float) * (size_t)N * NJ * hh * hw);
     /* ---- soft-argmax: handmvnet.py:182 */
     float *coords = falloc((size_t)N * NJ * 2);
@@ -687,7 +849,7 @@ int hmvo_forward(const hmvo_config *cfg, int B, int H, int W, const float *x, co
         }
         col += 10;
     }
-    for (int l = 0; l < 3; ++l) free(lv[l]);
+    for (int l = 0; l < 4; ++l) free(lv[l]);
     if (tokens_out) memcpy(tokens_out, tok, sizeof(float) * (size_t)N * NJ * d);
     /* ---- CrossAttentionFusion.forward: fusion.py:26-30 ; PositionalEncoding: layers.py:134-158 */
     int Tn = V * NJ;

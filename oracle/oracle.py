@@ -13,7 +13,7 @@ from typing import Dict, Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_BACKBONE = {"18": 0, "34": 1, "50_paper": 2}
+_BACKBONE = {"18": 0, "34": 1, "50_paper": 2, "w40": 3, "w64": 4}
 
 
 class _Cfg(ctypes.Structure):
@@ -127,7 +127,7 @@ class Oracle:
         }
         st = {}
         if stages:
-            fh = hs if cfg.is_paper else H // 16
+            fh = H // 4 if cfg.is_hrnet else (hs if cfg.is_paper else H // 16)
             st = {"feat0": np.zeros((B * V, cfg.backbone_channels[0], fh, fh), np.float32),
                   "coords_hm": np.zeros((B * V, 21, 2), np.float32),
                   "tokens": np.zeros((B, V * 21, d), np.float32),

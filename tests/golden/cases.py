@@ -28,6 +28,10 @@ CASES = {
     "r18_single_view": dict(bt="18", ch=[256, 128, 64], V=1, B=3, size=64, pos=ALL_POS, gcn=True, wseed=10, iseed=20),
     # more views than any release config (13 x 21 = 273 tokens)
     "r18_13views": dict(bt="18", ch=[256, 128, 64], V=13, B=1, size=64, pos=ALL_POS, gcn=False, wseed=11, iseed=21),
+    # HRNet-w40 / w64 backbones (6 of the 12 release configs use w40): 4 sampled levels, pose_net = 3x3 s2 conv
+    "hr40_tiny": dict(bt="w40", ch=[40, 80, 160, 320], V=2, B=1, size=64, pos=ALL_POS, gcn=True, wseed=12, iseed=22),
+    "hr40_v4_128": dict(bt="w40", ch=[40, 80, 160, 320], V=4, B=2, size=128, pos=["pos2d", "sin"], gcn=True, wseed=15, iseed=25),
+    "hr64_tiny": dict(bt="w64", ch=[64, 128, 256, 512], V=2, B=1, size=64, pos=ALL_POS, gcn=False, wseed=14, iseed=24),
     # non-power-of-two input, config constants that differ from the tensor shapes (handmvnet.py:252 quirk)
     "r50_odd_96": dict(bt="50_paper", ch=[1024], V=5, B=1, size=96, pos=ALL_POS, gcn=True, wseed=9, iseed=19,
                        image_size=200, heatmap_size=32),
@@ -37,7 +41,8 @@ CASES = {
 def case_params(spec: dict):
     """The three dicts the reference constructor takes (handmvnet.py:28)."""
     tp = {"debug": False, "root_relative": True}
-    mp = {"num_views": spec["V"], "backbone": "resnet", "backbone_type": spec["bt"],
+    mp = {"num_views": spec["V"], "backbone": "hrnet" if spec["bt"].startswith("w") else "resnet", "backbone_type": spec["bt"],
+          "backbone_pretrained_path": "",
           "backbone_channels": list(spec["ch"]), "backbone_pretrained": False, "backbone_early_return": 3,
           "freeze_bn": bool(spec.get("freeze_bn", False)), "pos_enc": list(spec["pos"]), "fusion": "cross_attn",
           "fusion_layers": int(spec.get("fusion_layers", 5)), "use_gcn": bool(spec["gcn"])}

@@ -62,8 +62,10 @@ def run_case(name: str, spec: dict, check_oracle: bool = True) -> dict:
 
     ref_mod.soft_argmax_2d = sa
     hooks = [
+        # feats[0] of handmvnet.py:165-180: last ResNet level (dict, reversed) | the tensor (r50-paper) | HRNet's list[0]
         model.backbone.register_forward_hook(lambda m, i, o: stages.__setitem__(
-            "feat0", (list(reversed([v for v in o.values() if v.dim() == 4]))[0] if isinstance(o, dict) else o).detach().clone())),
+            "feat0", (list(reversed([v for v in o.values() if v.dim() == 4]))[0] if isinstance(o, dict)
+                      else (o[0] if isinstance(o, (list, tuple)) else o)).detach().clone())),
         model.joints_late_fusion.register_forward_pre_hook(lambda m, i: stages.__setitem__("tokens", i[0].detach().clone())),
         model.joints_late_fusion.register_forward_hook(lambda m, i, o: stages.__setitem__("fused", o.detach().clone())),
     ]

@@ -41,12 +41,13 @@ WORKLOADS = {
     # name: (backbone_type, channels, V, B per GPU, size)
     "cfg3": ("50_paper", [1024], 8, 32, 256),      # BASELINE.json configs[2]
     "cfg2": ("18", [256, 128, 64], 4, 8, 256),     # BASELINE.json configs[1]
+    "hr40": ("w40", [40, 80, 160, 320], 8, 32, 256),   # the *_HR release configs' backbone at the headline shape
 }
 
 
 def params(bt, ch, V, B, size):
     tp = {"debug": False, "root_relative": True}
-    mp = {"num_views": V, "backbone": "resnet", "backbone_type": bt, "backbone_channels": ch, "backbone_pretrained": False,
+    mp = {"num_views": V, "backbone": "hrnet" if bt.startswith("w") else "resnet", "backbone_type": bt, "backbone_channels": ch, "backbone_pretrained": False,
           "backbone_early_return": 3, "pos_enc": ["pos2d", "crop", "sin"], "fusion": "cross_attn", "fusion_layers": 5,
           "use_gcn": True}
     dp = {"batch_size": B, "image_size": size, "heatmap_size": size // 8, "name": "dexycb"}
@@ -201,14 +202,16 @@ def main():
                     "launches_per_step": d["n"] // max(args.steps, 1), "avg_launch_ms": round(d["ms"] / d["n"], 4),
                     "flops_per_launch": d["flops"] / d["n"]}
         ms_step = elapsed / args.steps * 1e3
-        total_flops = forward_flops(cfg, B, size)
+        # dense algorithmic count for the ResNet workloads; for HRNet the executed FLOPs of the
+        # conv/GEMM launches of one step (the engine's own 2*M*N*K accounting)
+        total_flops = sum(r["flops"] for r in recs) / max(args.steps, 1) if cfg.is_hrnet else forward_flops(cfg, B, size)
         line = {
             "metric": "samples/sec (BxV frames) eval_fps.py, 8-view 256x256; 21-kpt L2 vs reference",
             "value": round(args.steps * B * V * world / elapsed, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{2 if args.workload == 'cfg3' else 1}]: B={B}/GPU x V={V} x {size}x{size}, "
-                                   f"resnet{bt} backbone, d={cfg.feat_dim}, cross_attn x{cfg.fusion_layers}, GCN decoder",
+            "config": {"workload": f"{'BASELINE configs[2]' if args.workload == 'cfg3' else ('BASELINE configs[1]' if args.workload == 'cfg2' else 'HRNet release-config backbone')}: B={B}/GPU x V={V} x {size}x{size}, "
+                                   f"{'hrnet_' if cfg.is_hrnet else 'resnet'}{bt} backbone, d={cfg.feat_dim}, cross_attn x{cfg.fusion_layers}, GCN decoder",
                        "global_batch": B * world, "views": V, "frame": size, "parallelism": f"sample-shard x{world}"},
             "roofline": roofline,
             "forward": {"algorithmic_gflop": round(total_flops / 1e9, 1),

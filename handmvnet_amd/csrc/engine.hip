@@ -42,6 +42,7 @@ struct HostTensor {
 struct Layer {
     float *w = nullptr, *bias = nullptr;
     int Cin = 0, Cout = 0, R = 1, S = 1, K = 0, Kpad = 0, Cout_pad = 0;
+    int Kreal = 0;      // reduction length without channel padding (FLOP accounting)
     bool f16 = false;   // operands (activations + packed weights) are fp16; bias stays fp32
     std::string label;
 };
@@ -310,6 +311,7 @@ struct Loader {
         };
         finish(L, label, cp, Cout, R, S, R * S * cp, wt, has_bn ? &sc : nullptr, has_bn ? &sh : nullptr,
                cb ? cb->data.data() : nullptr, f16);
+        L.Kreal = R * S * Cin;
     }
 
     // nn.Linear weight [out][in] (+ optional bias)
@@ -775,7 +777,7 @@ struct Runner {
             pr->name = L.f16 ? conv_tile_name_f16(tile, mode_) : conv_tile_name(tile, mode_);
             pr->label = L.label;
             // algorithmic FLOPs: the real (un-padded) reduction length; the stem's 4th channel is padding
-            const double kreal = (L.Cin < 32) ? (double)L.R * L.S * 3 : (double)L.K;
+            const double kreal = L.Kreal ? (double)L.Kreal : (double)L.K;   // real channels only (no padding FLOPs)
             pr->flops = 2.0 * (double)p.M * (double)L.Cout * kreal;
             check(hipEventRecord(pr->e0, s), "hipEventRecord");
         }

@@ -2,8 +2,10 @@
 
 Same constructor, same ``forward(x, bbox, cam_params) -> dict`` and the same ``state_dict``
 key layout as /root/reference/src/models/handmvnet.py:27-266, routed to the MI355X engine
-(libhandmv.so) through the C ABI of include/handmv.h.  Training hooks, losses, metrics and
-the MANO mesh step are outside the accelerated hot path.
+(libhandmv.so) through the C ABI of include/handmv.h.  The evaluation side of ``test_step``
+(handmvnet.py:352-383, 493-517: MPJPE / PA-MPJPE / PCK-AUC) runs on the device as well
+(handmvnet_amd/metrics.py); training hooks, losses and the MANO mesh step are outside the
+accelerated hot path.
 """
 from __future__ import annotations
 
@@ -40,6 +42,9 @@ class HandMvNet(torch.nn.Module):
         self.feat_dim = self.cfg.feat_dim
         self.pos_enc_list = list(self.cfg.pos_enc)
         self.fusion_layers = self.cfg.fusion_layers
+        self.get_vertices = model_params.get("get_vertices", False)
+        # handmvnet.py:117-125 (config_from_params has already rejected unknown dataset names)
+        self.auc_thresh = {"dexycb": [0.0, 0.02], "ho3d": [0.0, 0.05], "mvhand": [0.0, 0.02]}[data_params.get("name", "dexycb")]
         self.example_input_array = {  # handmvnet.py:110-115 ("just for summary")
             "x": torch.zeros(2, self.num_views, 3, 256, 256), "bbox": torch.zeros(2, self.num_views, 4),
             "cam_params": {"intrinsic": torch.zeros(2, self.num_views, 4), "extrinsic": torch.zeros(2, self.num_views, 4, 4)}}
@@ -191,6 +196,41 @@ class HandMvNet(torch.nn.Module):
         _lib.check(rc, h)
         self._last_key = (hh, ww, dev.index if dev.index is not None else torch.cuda.current_device(), batch, self._dtype)
         return {"joints_crop_img": out_crop, "joints_cam": out_cam, "heatmap": out_hm}
+
+    # ------------------------------------------------------------------ evaluation (handmvnet.py:352-383, 493-517)
+    def _get_metrics(self, pred_pts, target_pts):
+        """handmvnet.py:352-368: (mpjpe mm, pa_mpjpe mm, auc, norm_auc, pck_values, thresholds) for [b, n, 3]
+        point sets in metres -- one device launch, one device->host copy."""
+        from .metrics import PoseMetrics
+        scale = 1000
+        mpjpe, pa_mpjpe, auc, norm_auc, pck_values, thresholds = PoseMetrics.all_metrics(
+            pred_pts, target_pts, min_threshold=self.auc_thresh[0], max_threshold=self.auc_thresh[1], steps=20)
+        return mpjpe * scale, pa_mpjpe * scale, auc, norm_auc, pck_values, thresholds
+
+    def _calculate_mpjpe(self, out, inputs, mode="train"):
+        """handmvnet.py:370-427 without the Lightning logging; the MANO vertex metrics need manopth (absent)."""
+        from .metrics import PoseMetrics
+        pred2d, gt2d = out["joints_crop_img"], inputs["joints_crop_img"].to(out["joints_crop_img"].device)
+        if "joints_img_mask" in inputs:   # models/utils.py:123-131: masked joints are zeroed on both sides
+            keep = (~inputs["joints_img_mask"].to(pred2d.device)).unsqueeze(-1)
+            pred2d, gt2d = pred2d * keep, gt2d * keep
+        mpjpe, pa_mpjpe, auc_j, norm_auc_j, pck_values_j, _ = self._get_metrics(out["joints_cam"], inputs["joints_cam"])
+        out_metrics = {f"{mode}_mpjpe2d": PoseMetrics.mpjpe(pred2d, gt2d), f"{mode}_mpjpe": mpjpe,
+                       f"{mode}_pa_mpjpe": pa_mpjpe, f"{mode}_pck_j": pck_values_j, f"{mode}_auc_j": auc_j,
+                       f"{mode}_norm_auc_j": norm_auc_j}
+        if self.get_vertices:
+            raise NotImplementedError("get_vertices needs manopth + MANO assets (joints_to_vertices.py:14-23), absent here")
+        return out_metrics
+
+    def test_step(self, batch, batch_idx=0):
+        """handmvnet.py:493-517: forward + metrics.  The training losses are not part of this build, so "loss" is
+        None.  Like the reference, converts inputs["joints_cam"] / ["root_joint"] from mm to metres IN PLACE."""
+        inputs = batch["data"]
+        out = self.forward(inputs["rgb"], inputs["bboxes"], batch["cam_params"])
+        inputs["joints_cam"] /= 1000
+        if "root_joint" in inputs:
+            inputs["root_joint"] /= 1000
+        return {"loss": None, "metrics": self._calculate_mpjpe(out, inputs, mode="test")}
 
     # ------------------------------------------------------------------ introspection (tests / bench)
     def capture_stages(self, enable: bool = True):

@@ -126,6 +126,18 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
 int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t R, int32_t S,
                    int32_t stride, int32_t pad, int32_t with_residual, int32_t tile, int32_t iters, float *avg_ms);
 
+/* Evaluation metrics of HandMvNet._get_metrics (handmvnet.py:352-368) on the device, replacing
+ * PoseMetrics.mpjpe / pa_mpjpe / pck / pck_auc / compute_similarity_transform (models/metrics.py:6-24, 64-176).
+ * pred, target: device fp32 [n_sets][n_pts][dim] (dim 2 or 3; units as given -- the caller applies the x1000 the
+ * reference applies).  Thresholds = torch.linspace(thr_min, thr_max, steps), 1 <= steps <= 256.
+ * procrustes != 0 (dim == 3 only): also the similarity-aligned error; aligned (device [n_sets][n_pts][3] or NULL)
+ * receives the aligned predictions.  result: device fp32 [4 + 2*steps] =
+ *   { mpjpe, pa_mpjpe (NaN if not requested), auc, norm_auc, pck[steps], thresholds[steps] }.
+ * Asynchronous on `stream`; one single-workgroup launch with fixed-order reductions (bit-reproducible). */
+int hmv_pose_metrics(int32_t device, const float *pred, const float *target, int32_t n_sets, int32_t n_pts, int32_t dim,
+                     float thr_min, float thr_max, int32_t steps, int32_t procrustes, float *aligned, float *result,
+                     void *stream);
+
 const char *hmv_version(void);
 
 #ifdef __cplusplus

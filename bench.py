@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"], help="f16 = BASELINE configs[4] (fp16 conv stack)")
+    ap.add_argument("--input", default="nchw", choices=["nchw", "frames"],
+                    help="nchw = prepared fp32 batch (eval_fps.py protocol, the headline); frames = raw uint8 480x640 camera "
+                         "frames + crop windows through hmv_forward_frames (SURVEY 8(f) row 4)")
     ap.add_argument("--per-layer", default="", help="write per-layer launch timings (JSON) to this file")
     args = ap.parse_args()
 
@@ -145,8 +148,15 @@ def main():
     cam = {"intrinsic": it}
     model.reserve(B, size, size, dev)
 
+    if args.input == "frames":   # ho3d.py:26 camera resolution; windows like batch_center_scale_to_box makes them
+        g = torch.Generator(device=dev).manual_seed(2000 + rank)
+        raw = torch.randint(0, 256, (B, V, 480, 640, 3), dtype=torch.uint8, device=dev, generator=g)
+        side = torch.randint(150, 400, (B, V, 1), device=dev, generator=g)
+        org = torch.randint(-40, 300, (B, V, 2), device=dev, generator=g)
+        crop_boxes = torch.cat([org, org + side], dim=-1).int()
+
     def step():
-        out = model(xt, bt_, cam)
+        out = model.forward_frames(raw, crop_boxes, cam, image_size=size) if args.input == "frames" else model(xt, bt_, cam)
         return gather_outputs(out) if world > 1 else out
 
     for _ in range(args.warmup):
@@ -209,7 +219,8 @@ def main():
             "metric": "samples/sec (BxV frames) eval_fps.py, 8-view 256x256; 21-kpt L2 vs reference",
             "value": round(args.steps * B * V * world / elapsed, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic" if args.input == "nchw" else "synthetic uint8 480x640 frames + crop windows (prepared on the device)",
             "config": {"workload": f"{'BASELINE configs[2]' if args.workload == 'cfg3' else ('BASELINE configs[1]' if args.workload == 'cfg2' else 'HRNet release-config backbone')}: B={B}/GPU x V={V} x {size}x{size}, "
                                    f"{'hrnet_' if cfg.is_hrnet else 'resnet'}{bt} backbone, d={cfg.feat_dim}, cross_attn x{cfg.fusion_layers}, GCN decoder",
                        "global_batch": B * world, "views": V, "frame": size, "parallelism": f"sample-shard x{world}"},

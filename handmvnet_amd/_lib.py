@@ -11,7 +11,8 @@ LIB_PATH = os.environ.get("HMV_LIB") or os.path.join(_HERE, "libhandmv.so")   # 
 # every symbol include/handmv.h declares
 SYMBOLS = ["hmv_create", "hmv_set_tensor", "hmv_finalize_weights", "hmv_workspace_bytes", "hmv_reserve", "hmv_forward",
            "hmv_last_error", "hmv_destroy", "hmv_set_capture", "hmv_read_stage", "hmv_set_profiling", "hmv_profile_count",
-           "hmv_profile_get", "hmv_op_conv2d", "hmv_bench_conv", "hmv_pose_metrics", "hmv_version"]
+           "hmv_profile_get", "hmv_op_conv2d", "hmv_bench_conv", "hmv_pose_metrics", "hmv_forward_frames",
+           "hmv_op_prepare_frames", "hmv_version"]
 
 HMV_OK = 0
 
@@ -63,6 +64,12 @@ def load() -> ctypes.CDLL:
     lib.hmv_bench_conv.restype = ctypes.c_int
     lib.hmv_pose_metrics.argtypes = [ci, fp, fp, ci, ci, ci, ctypes.c_float, ctypes.c_float, ci, ci, fp, fp, vp]
     lib.hmv_pose_metrics.restype = ctypes.c_int
+    lib.hmv_forward_frames.argtypes = [vp, ci, fp, ci, ci, fp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                       fp, fp, fp, fp, fp, vp]
+    lib.hmv_forward_frames.restype = ctypes.c_int
+    lib.hmv_op_prepare_frames.argtypes = [ci, fp, ci, ci, ci, fp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                          ci, ci, fp, vp]
+    lib.hmv_op_prepare_frames.restype = ctypes.c_int
     lib.hmv_version.restype = ctypes.c_char_p
     for name in ("hmv_create", "hmv_set_tensor", "hmv_finalize_weights", "hmv_reserve", "hmv_forward", "hmv_set_capture",
                  "hmv_read_stage", "hmv_set_profiling", "hmv_profile_count", "hmv_profile_get", "hmv_op_conv2d"):

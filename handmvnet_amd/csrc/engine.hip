@@ -169,6 +169,14 @@ struct hmv_engine {
     float *cap_feat0 = nullptr, *cap_coords = nullptr, *cap_tokens = nullptr, *cap_fused = nullptr;
     size_t cap_feat0_n = 0, cap_coords_n = 0, cap_tokens_n = 0, cap_fused_n = 0;
 
+    // set only for the duration of hmv_forward_frames: raw camera frames instead of prepared NCHW input
+    struct FrameSrc {
+        const uint8_t *frames = nullptr;
+        const int *boxes = nullptr;
+        int fh = 0, fw = 0;
+        float mean[3] = {0, 0, 0}, std[3] = {1, 1, 1};
+    } fsrc;
+
     bool profiling = false;
     std::vector<ProfRec> prof;
     size_t prof_used = 0;
@@ -812,7 +820,8 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         // ================= HighResolutionNet.forward (hrnet.py:357-393) =================
         const HrNet &hr = h->hr;
         float *in4 = R.alloc((size_t)N * H * W * 4);
-        LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
+        if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, false, in4, s));
+        else LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
         const int H1 = (H + 2 - 3) / 2 + 1, W1 = (W + 2 - 3) / 2 + 1, H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
         float *c1 = R.alloc((size_t)N * H1 * W1 * 64);
         R.conv(hr.conv1, in4, N, H, W, 2, 1, 1, c1, 64, nullptr, 0, ACT_RELU, H1, W1);
@@ -949,7 +958,8 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     } else {
     // ---- stem: conv1 7x7 s2 + BN + ReLU, maxpool 3x3 s2 (resnet.py:218-221)
     float *in4 = R.alloc((size_t)N * H * W * 4);   // NHWC4 fp32 and NHWC8 fp16 are both 16 bytes per pixel
-    if (h16) LAUNCH(launch_nchw_to_nhwc8_f16(x, in4, N, H, W, s));
+    if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, h16, in4, s));
+    else if (h16) LAUNCH(launch_nchw_to_nhwc8_f16(x, in4, N, H, W, s));
     else LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
     const int H1 = (H + 6 - 7) / 2 + 1, W1 = (W + 6 - 7) / 2 + 1;
     float *c1 = R.alloc(ACT((size_t)N * H1 * W1 * 64));
@@ -1196,11 +1206,8 @@ int hmv_reserve(hmv_handle h, int32_t batch) {
     return ensure_capture(h, batch);
 }
 
-int hmv_forward(hmv_handle h, int32_t batch, const float *x, const float *bbox, const float *intrinsic, float *joints_crop_img,
-                float *joints_cam, float *heatmap, void *stream) {
-    if (!h) return HMV_ERR_ARG;
-    if (!h->finalized) return h->fail(HMV_ERR_STATE, "hmv_finalize_weights has not succeeded on this handle");
-    if (batch <= 0 || !x || !joints_crop_img || !joints_cam) return h->fail(HMV_ERR_ARG, "null or empty input/output");
+static int forward_common(hmv_handle h, int32_t batch, const float *x, const float *bbox, const float *intrinsic,
+                          float *joints_crop_img, float *joints_cam, float *heatmap, void *stream) {
     if ((h->cfg.pos_enc & HMV_POS_CROP) && (!bbox || !intrinsic))
         return h->fail(HMV_ERR_ARG, "pos_enc contains 'crop': bbox and cam_params['intrinsic'] are required");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1213,6 +1220,45 @@ int hmv_forward(hmv_handle h, int32_t batch, const float *x, const float *bbox, 
                                false, h->plan);
     if (rc == HMV_OK && h->plan.high > h->arena_bytes) return h->fail(HMV_ERR_STATE, "workspace plan exceeded its reservation");
     return rc;
+}
+
+int hmv_forward(hmv_handle h, int32_t batch, const float *x, const float *bbox, const float *intrinsic, float *joints_crop_img,
+                float *joints_cam, float *heatmap, void *stream) {
+    if (!h) return HMV_ERR_ARG;
+    if (!h->finalized) return h->fail(HMV_ERR_STATE, "hmv_finalize_weights has not succeeded on this handle");
+    if (batch <= 0 || !x || !joints_crop_img || !joints_cam) return h->fail(HMV_ERR_ARG, "null or empty input/output");
+    return forward_common(h, batch, x, bbox, intrinsic, joints_crop_img, joints_cam, heatmap, stream);
+}
+
+int hmv_forward_frames(hmv_handle h, int32_t batch, const uint8_t *frames, int32_t frame_h, int32_t frame_w, const int32_t *crop_boxes,
+                       const float *mean, const float *std, const float *bbox, const float *intrinsic, float *joints_crop_img,
+                       float *joints_cam, float *heatmap, void *stream) {
+    if (!h) return HMV_ERR_ARG;
+    if (!h->finalized) return h->fail(HMV_ERR_STATE, "hmv_finalize_weights has not succeeded on this handle");
+    if (batch <= 0 || !frames || !crop_boxes || !mean || !std || !joints_crop_img || !joints_cam)
+        return h->fail(HMV_ERR_ARG, "null or empty input/output");
+    if (frame_h <= 0 || frame_w <= 0) return h->fail(HMV_ERR_ARG, "frame size must be positive");
+    for (int c = 0; c < 3; ++c)
+        if (!(std[c] > 0.f)) return h->fail(HMV_ERR_ARG, "std must be positive");
+    h->fsrc.frames = frames;
+    h->fsrc.boxes = crop_boxes;
+    h->fsrc.fh = frame_h;
+    h->fsrc.fw = frame_w;
+    for (int c = 0; c < 3; ++c) { h->fsrc.mean[c] = mean[c]; h->fsrc.std[c] = std[c]; }
+    const int rc = forward_common(h, batch, nullptr, bbox, intrinsic, joints_crop_img, joints_cam, heatmap, stream);
+    h->fsrc.frames = nullptr;
+    h->fsrc.boxes = nullptr;
+    return rc;
+}
+
+int hmv_op_prepare_frames(int32_t device, const uint8_t *frames, int32_t n_frames, int32_t frame_h, int32_t frame_w,
+                          const int32_t *crop_boxes, const float *mean, const float *std, int32_t out_h, int32_t out_w, float *out_nhwc4,
+                          void *stream) {
+    if (!frames || !crop_boxes || !mean || !std || !out_nhwc4 || n_frames <= 0 || frame_h <= 0 || frame_w <= 0 || out_h <= 0 || out_w <= 0)
+        return HMV_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return HMV_ERR_HIP;
+    return launch_frames_to_input(frames, crop_boxes, n_frames, frame_h, frame_w, out_h, out_w, mean, std, false, out_nhwc4,
+                                  static_cast<hipStream_t>(stream)) == hipSuccess ? HMV_OK : HMV_ERR_HIP;
 }
 
 void hmv_destroy(hmv_handle h) {

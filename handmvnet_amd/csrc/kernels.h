@@ -60,6 +60,9 @@ hipError_t launch_sample_gather(const float *feat, int N, int H, int W, int C, c
                                 hipStream_t s, int elem_bytes = 4);
 // fp16 path (BASELINE configs[4])
 hipError_t launch_nchw_to_nhwc8_f16(const float *x, void *out, int N, int H, int W, hipStream_t s);
+// uint8 HWC camera frames + integer crop windows -> normalised NHWC4 fp32 / NHWC8 fp16 stem input (ho3d.py:35-40, 136-149)
+hipError_t launch_frames_to_input(const uint8_t *frames, const int *boxes, int N, int Hf, int Wf, int S_h, int S_w, const float *mean,
+                                  const float *std, bool f16, void *out, hipStream_t s);
 hipError_t launch_maxpool3s2_f16(const void *in, void *out, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 hipError_t launch_nhwc_f16_to_nchw(const void *in, float *out, int N, int H, int W, int C, hipStream_t s);
 // tokens[(n*21+j)][col0 + c] = sum_t w_t * s[(n*21+j)*4+t][c]

@@ -566,4 +566,87 @@ hipError_t launch_copy_rows(const float *in, int ldi, float *out, int ldo, int r
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ camera frames: uint8 HWC -> model input
+// The reference prepares every view on the host (datasets/ho3d.py:35-40, 136-149; datasets/utils.py:40-77):
+//   crop_and_pad_image(frame, box) -> ToTensor (/255) -> Resize((S, S), antialias=True) -> Normalize(mean, std).
+// Here it is one kernel from the raw frames to the stem conv's channels-last input (NHWC4 fp32 / NHWC8 fp16): a
+// lane owns one output pixel, walks the separable triangle filter of torch's antialiased bilinear resize
+// (aten `_compute_indices_min_size_weights_aa`: support = max(scale, 1), weights 1 - |x| / max(scale, 1),
+// renormalised over the taps that fall inside the window) and reads window pixels that leave the frame as 0.
+// An empty box (x2 <= x1 or y2 <= y1) is the reference's "no visible joint" black view.
+struct FrameNorm { float mean[3], inv_std[3]; };
+
+__device__ __forceinline__ void aa_span(int o, int in_size, float scale, float &center, float &invscale, int &first, int &count) {
+    const float support = scale >= 1.f ? scale : 1.f;
+    invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    center = scale * ((float)o + 0.5f);
+    first = max((int)(center - support + 0.5f), 0);
+    count = min((int)(center + support + 0.5f), in_size) - first;
+}
+
+template <bool F16>
+__global__ void frames_to_input_kernel(const uint8_t *__restrict__ frames, const int *__restrict__ boxes, int Hf, int Wf, int S_h,
+                                       int S_w, FrameNorm nm, void *__restrict__ out, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int ox = (int)(i % S_w);
+        size_t t = i / S_w;
+        const int oy = (int)(t % S_h);
+        const size_t n = t / S_h;
+        const int x1 = boxes[n * 4], y1 = boxes[n * 4 + 1], x2 = boxes[n * 4 + 2], y2 = boxes[n * 4 + 3];
+        float acc[3] = {0.f, 0.f, 0.f};
+        if (x2 > x1 && y2 > y1) {
+            const int cw = x2 - x1, ch = y2 - y1;
+            float cx, ix, cy, iy;
+            int fx, nx, fy, ny;
+            aa_span(ox, cw, (float)cw / (float)S_w, cx, ix, fx, nx);
+            aa_span(oy, ch, (float)ch / (float)S_h, cy, iy, fy, ny);
+            const uint8_t *img = frames + n * (size_t)Hf * Wf * 3;
+            float wysum = 0.f, wxsum = 0.f;
+            for (int a = 0; a < nx; ++a) wxsum += fmaxf(0.f, 1.f - fabsf((float)(a + fx) - cx + 0.5f) * ix);
+            for (int b = 0; b < ny; ++b) {
+                const float wy = fmaxf(0.f, 1.f - fabsf((float)(b + fy) - cy + 0.5f) * iy);
+                wysum += wy;
+                const int sy = fy + b + y1;
+                if ((unsigned)sy >= (unsigned)Hf || wy == 0.f) continue;
+                float row[3] = {0.f, 0.f, 0.f};
+                for (int a = 0; a < nx; ++a) {
+                    const int sx = fx + a + x1;
+                    if ((unsigned)sx >= (unsigned)Wf) continue;
+                    const float wx = fmaxf(0.f, 1.f - fabsf((float)(a + fx) - cx + 0.5f) * ix);
+                    const uint8_t *px = img + ((size_t)sy * Wf + sx) * 3;
+                    row[0] += wx * (float)px[0];
+                    row[1] += wx * (float)px[1];
+                    row[2] += wx * (float)px[2];
+                }
+                acc[0] += wy * row[0];
+                acc[1] += wy * row[1];
+                acc[2] += wy * row[2];
+            }
+            const float k = 1.f / (wxsum * wysum * 255.f);
+            acc[0] *= k; acc[1] *= k; acc[2] *= k;
+        }
+        const float r = (acc[0] - nm.mean[0]) * nm.inv_std[0], g = (acc[1] - nm.mean[1]) * nm.inv_std[1],
+                    b = (acc[2] - nm.mean[2]) * nm.inv_std[2];
+        if (F16) {
+            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            v[0] = (_Float16)r; v[1] = (_Float16)g; v[2] = (_Float16)b;
+            reinterpret_cast<f16x8 *>(out)[i] = v;
+        } else {
+            reinterpret_cast<f32x4 *>(out)[i] = f32x4{r, g, b, 0.f};
+        }
+    }
+}
+hipError_t launch_frames_to_input(const uint8_t *frames, const int *boxes, int N, int Hf, int Wf, int S_h, int S_w, const float *mean,
+                                  const float *std, bool f16, void *out, hipStream_t s) {
+    FrameNorm nm;
+    for (int c = 0; c < 3; ++c) { nm.mean[c] = mean[c]; nm.inv_std[c] = 1.f / std[c]; }
+    const size_t total = (size_t)N * S_h * S_w;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (f16) hipLaunchKernelGGL(frames_to_input_kernel<true>, dim3(grid), dim3(256), 0, s, frames, boxes, Hf, Wf, S_h, S_w, nm, out, total);
+    else hipLaunchKernelGGL(frames_to_input_kernel<false>, dim3(grid), dim3(256), 0, s, frames, boxes, Hf, Wf, S_h, S_w, nm, out, total);
+    return hipGetLastError();
+}
+
 }  // namespace hmv

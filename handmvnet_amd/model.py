@@ -197,6 +197,50 @@ class HandMvNet(torch.nn.Module):
         self._last_key = (hh, ww, dev.index if dev.index is not None else torch.cuda.current_device(), batch, self._dtype)
         return {"joints_crop_img": out_crop, "joints_cam": out_cam, "heatmap": out_hm}
 
+    def forward_frames(self, frames, crop_boxes, cam_params=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
+                       image_size=None):
+        """forward() from raw camera frames: `frames` uint8 [b, v, Hf, Wf, 3] and integer crop windows `crop_boxes`
+        [b, v, 4] (x1, y1, x2, y2; may leave the frame, empty = black view) replace the reference's host-side
+        crop_and_pad_image -> ToTensor -> Resize(antialias=True) -> Normalize (datasets/ho3d.py:35-40, 136-149); the
+        windows also serve as `bbox` for the crop-FoV columns (ho3d.py:198).  Same return dict as forward()."""
+        if not isinstance(frames, torch.Tensor) or frames.dim() != 5 or frames.shape[-1] != 3 or frames.dtype != torch.uint8:
+            raise ValueError("frames must be a uint8 [b, v, Hf, Wf, 3] tensor")
+        if not frames.is_cuda:
+            raise _lib.HandMvError("handmvnet_amd runs on MI355X only: frames must be a CUDA(HIP) tensor (no CPU fallback)")
+        b, v, fh, fw, _ = frames.shape
+        n = b * v
+        if n % self.num_views:
+            raise RuntimeError(f"shape '[-1, {self.num_views}, ...]' is invalid for input of {n} frames")
+        batch = n // self.num_views
+        dev = frames.device
+        size = int(image_size or self.cfg.image_size)
+        frames = frames.contiguous()
+        boxes = crop_boxes.to(dev).reshape(-1, 4).to(torch.int32).contiguous()
+        if boxes.shape[0] != n:
+            raise RuntimeError("crop_boxes must hold one row per frame")
+        bb = it = None
+        if "crop" in self.cfg.pos_enc:
+            if cam_params is None:
+                raise TypeError("pos_enc contains 'crop': cam_params['intrinsic'] is required")
+            bb = boxes.float()
+            it = cam_params["intrinsic"].to(dev).reshape(-1, 4).contiguous().float()
+            if it.shape[0] != n:
+                raise RuntimeError("intrinsic must hold one row per frame")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        h = self._engine(size, size, idx)
+        out_crop = torch.empty(batch, self.num_views, 21, 2, device=dev, dtype=torch.float32)
+        out_cam = torch.empty(batch, 21, 3, device=dev, dtype=torch.float32)
+        out_hm = torch.empty(batch, self.num_views, 21, size // 8, size // 8, device=dev, dtype=torch.float32)
+        m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = _lib.load().hmv_forward_frames(h, batch, frames.data_ptr(), fh, fw, boxes.data_ptr(), m3, s3,
+                                                bb.data_ptr() if bb is not None else None, it.data_ptr() if it is not None else None,
+                                                out_crop.data_ptr(), out_cam.data_ptr(), out_hm.data_ptr(), ctypes.c_void_p(stream))
+        _lib.check(rc, h)
+        self._last_key = (size, size, idx, batch, self._dtype)
+        return {"joints_crop_img": out_crop, "joints_cam": out_cam, "heatmap": out_hm}
+
     # ------------------------------------------------------------------ evaluation (handmvnet.py:352-383, 493-517)
     def _get_metrics(self, pred_pts, target_pts):
         """handmvnet.py:352-368: (mpjpe mm, pa_mpjpe mm, auc, norm_auc, pck_values, thresholds) for [b, n, 3]

@@ -126,6 +126,23 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
 int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t R, int32_t S,
                    int32_t stride, int32_t pad, int32_t with_residual, int32_t tile, int32_t iters, float *avg_ms);
 
+/* hmv_forward from raw camera frames: the reference prepares every view on DataLoader workers
+ * (datasets/ho3d.py:35-40, 136-149: crop_and_pad_image (datasets/utils.py:40-77) -> ToTensor -> Resize((S,S), antialias=True)
+ * -> Normalize(mean, std)); here that is one kernel in front of the stem conv and the fp32 NCHW batch never exists.
+ * frames: device uint8 [batch*V][frame_h][frame_w][3] (HWC, the channel order the weights were trained on);
+ * crop_boxes: device int32 [batch*V][4] = x1,y1,x2,y2 of the (square or not) crop window in frame pixels -- may leave the
+ * frame (zeros are read there); an EMPTY window (x2<=x1 or y2<=y1) yields the reference's black "no visible joint" view;
+ * mean/std: host float[3] (ho3d.py:38-39 uses the ImageNet constants).  The window is resized to cfg.height x cfg.width.
+ * bbox / intrinsic / outputs / stream exactly as hmv_forward (bbox is normally crop_boxes as fp32, ho3d.py:198). */
+int hmv_forward_frames(hmv_handle h, int32_t batch, const uint8_t *frames, int32_t frame_h, int32_t frame_w, const int32_t *crop_boxes,
+                       const float *mean, const float *std, const float *bbox, const float *intrinsic, float *joints_crop_img,
+                       float *joints_cam, float *heatmap, void *stream);
+
+/* The frame preparation alone (op-level parity tests): out_nhwc4 device fp32 [n_frames][out_h][out_w][4] (4th channel 0). */
+int hmv_op_prepare_frames(int32_t device, const uint8_t *frames, int32_t n_frames, int32_t frame_h, int32_t frame_w,
+                          const int32_t *crop_boxes, const float *mean, const float *std, int32_t out_h, int32_t out_w, float *out_nhwc4,
+                          void *stream);
+
 /* Evaluation metrics of HandMvNet._get_metrics (handmvnet.py:352-368) on the device, replacing
  * PoseMetrics.mpjpe / pa_mpjpe / pck / pck_auc / compute_similarity_transform (models/metrics.py:6-24, 64-176).
  * pred, target: device fp32 [n_sets][n_pts][dim] (dim 2 or 3; units as given -- the caller applies the x1000 the

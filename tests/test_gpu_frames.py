@@ -1,0 +1,115 @@
+"""GPU parity of the frame preparation (uint8 camera frames -> model input):
+  (1) hmv_op_prepare_frames against the reference fixture (crop_and_pad_image of the real reference + torch's
+      antialiased resize) and against the numpy oracle on fresh inputs;
+  (2) hmv_forward_frames == hmv_forward on the oracle-prepared batch, end to end;
+  (3) properties at full size: determinism, per-frame independence, value range.
+Tolerance: 5e-6 in normalised units for the op (fp32 filter arithmetic in a different summation order);
+joints_cam of the fused path within 1e-4 rel-L2 of the two-step path.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_case, rel_l2
+from oracle import frames_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = np.load(os.path.join(ROOT, "tests", "golden", "frames_cases.npz"))
+NAMES = sorted({k.split(".")[0] for k in FIX.files})
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_prepare_frames_matches_reference_fixture(name):
+    from handmvnet_amd.frames import prepare_frames
+    got = prepare_frames(_dev(FIX[f"{name}.frames"]), _dev(FIX[f"{name}.boxes"]), int(FIX[f"{name}.size"]))
+    assert tuple(got.shape) == FIX[f"{name}.out"].shape
+    assert np.abs(got.cpu().numpy() - FIX[f"{name}.out"]).max() < 5e-6
+
+
+def test_prepare_frames_matches_oracle_on_camera_sized_frames():
+    """480x640 frames (ho3d.py:26), windows like batch_center_scale_to_box produces, 256x256 output."""
+    from handmvnet_amd.frames import prepare_frames
+    rng = np.random.default_rng(11)
+    frames = rng.integers(0, 256, (2, 3, 480, 640, 3), dtype=np.uint8)
+    side = rng.integers(90, 420, (2, 3))
+    cx, cy = rng.integers(0, 640, (2, 3)), rng.integers(0, 480, (2, 3))
+    boxes = np.stack([cx - side // 2, cy - side // 2, cx - side // 2 + side, cy - side // 2 + side], axis=-1).astype(np.int32)
+    boxes[1, 2] = [700, 500, 900, 700]                      # entirely outside the frame: all zeros before Normalize
+    got = prepare_frames(_dev(frames), _dev(boxes), 256).cpu().numpy()
+    want = fo.prepare_batch(frames, boxes, 256)
+    assert got.shape == (2, 3, 3, 256, 256)
+    assert np.abs(got - want).max() < 5e-6
+    assert np.allclose(got[1, 2], ((0 - fo.MEAN) / fo.STD)[:, None, None])
+
+
+@pytest.mark.parametrize("name,half", [("tiny_r18", False), ("cfg1_r50_v4_128", False), ("hr40_tiny", False), ("tiny_r50", True)])
+def test_forward_frames_equals_forward_on_prepared_batch(name, half):
+    from handmvnet_amd import HandMvNet
+    cfg, (tp, mp, dp), sd, (x, bbox, intr), fx = load_case(name)
+    b, v, size = x.shape[0], x.shape[1], x.shape[-1]
+    rng = np.random.default_rng(17)
+    frames = rng.integers(0, 256, (b, v, 120, 160, 3), dtype=np.uint8)
+    # smooth the noise a little so that the heat maps are not pathologically flat
+    frames = ((frames.astype(np.float32) + np.roll(frames, 1, 2) + np.roll(frames, 1, 3)) / 3).astype(np.uint8)
+    side = rng.integers(50, 140, (b, v))
+    x1, y1 = rng.integers(-20, 100, (b, v)), rng.integers(-20, 60, (b, v))
+    boxes = np.stack([x1, y1, x1 + side, y1 + side], axis=-1).astype(np.int32)
+    m = HandMvNet(tp, mp, dp)
+    m.load_state_dict(sd, strict=True)
+    m.to("cuda").eval()
+    if half:
+        m.half()
+    cam = {"intrinsic": _dev(intr)}
+    two_step = m(_dev(fo.prepare_batch(frames, boxes, size)), _dev(boxes.astype(np.float32)), cam)
+    fused = m.forward_frames(_dev(frames), _dev(boxes), cam, image_size=size)
+    torch.cuda.synchronize()
+    assert set(fused) == {"joints_crop_img", "joints_cam", "heatmap"}
+    tol = 2e-3 if half else 1e-4
+    assert rel_l2(fused["joints_cam"].cpu().numpy(), two_step["joints_cam"].cpu().numpy()) < tol
+    assert np.abs(fused["joints_crop_img"].cpu().numpy() - two_step["joints_crop_img"].cpu().numpy()).max() < (0.5 if half else 0.02)
+    assert rel_l2(fused["heatmap"].cpu().numpy(), two_step["heatmap"].cpu().numpy()) < (5e-3 if half else 1e-4)
+
+
+def test_prepare_frames_full_size_properties():
+    """BASELINE-sized batch (256 frames of 480x640 -> 256x256): deterministic, every frame independent of its
+    neighbours, output bounded by the normalised range of [0, 255]."""
+    from handmvnet_amd.frames import prepare_frames
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    frames = torch.randint(0, 256, (32, 8, 480, 640, 3), dtype=torch.uint8, device="cuda:0", generator=g)
+    side = torch.randint(100, 400, (32, 8, 1), device="cuda:0", generator=g)
+    org = torch.randint(-50, 400, (32, 8, 2), device="cuda:0", generator=g)
+    boxes = torch.cat([org, org + side], dim=-1).int()
+    a = prepare_frames(frames, boxes, 256)
+    b = prepare_frames(frames, boxes, 256)
+    assert torch.equal(a, b)
+    sub = prepare_frames(frames[5:6, 2:5], boxes[5:6, 2:5], 256)
+    assert torch.equal(sub, a[5:6, 2:5])
+    lo = torch.tensor([(0 - m) / s for m, s in zip(fo.MEAN, fo.STD)], device="cuda:0").view(1, 1, 3, 1, 1)
+    hi = torch.tensor([(1 - m) / s for m, s in zip(fo.MEAN, fo.STD)], device="cuda:0").view(1, 1, 3, 1, 1)
+    assert bool(((a >= lo - 1e-5) & (a <= hi + 1e-5)).all())
+
+
+def test_forward_frames_argument_errors():
+    from handmvnet_amd import HandMvNet, _lib
+    cfg, (tp, mp, dp), sd, (x, bbox, intr), fx = load_case("tiny_r18")
+    m = HandMvNet(tp, mp, dp).to("cuda").eval()
+    frames = torch.zeros(1, 2, 32, 32, 3, dtype=torch.uint8, device="cuda:0")
+    boxes = torch.tensor([[[0, 0, 32, 32], [0, 0, 32, 32]]], device="cuda:0")
+    with pytest.raises(ValueError):
+        m.forward_frames(frames.float(), boxes, {"intrinsic": _dev(intr)})
+    with pytest.raises(_lib.HandMvError):
+        m.forward_frames(frames.cpu(), boxes, {"intrinsic": _dev(intr)})
+    with pytest.raises(TypeError):
+        m.forward_frames(frames, boxes, None)                      # 'crop' in pos_enc needs intrinsics
+    with pytest.raises(RuntimeError):
+        m.forward_frames(frames, boxes[:, :1], {"intrinsic": _dev(intr)})
+    with pytest.raises(_lib.HandMvError):
+        m.forward_frames(frames, boxes, {"intrinsic": _dev(intr)}, std=(0.2, 0.0, 0.2))

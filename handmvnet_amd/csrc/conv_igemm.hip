@@ -35,6 +35,7 @@
 //     activation tile is pulled from HBM once per XCD and re-read from that XCD's L2.
 //   * epilogue fused: folded-BN shift / bias, residual add, ReLU / GELU(erf) / LeakyReLU, staged
 //     through LDS so that global traffic is 16-byte vectors on full output rows.
+#include <cstdio>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -46,7 +47,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;   // K granularity of the packed weights (Kpad % 32 == 0); kernels step by KB = 16 or 32
+
 #ifndef HMV_UB
 #define HMV_UB 4   // output rows (16-byte vectors) in flight per thread in the epilogue
 #endif
@@ -63,7 +64,9 @@ static hipError_t ensure_zero_page() {
 // A-operand addressing modes
 enum { MODE_TAPS = 0,   // general R x S convolution, Cin % 32 == 0: the tap of a k-step is wave-uniform
        MODE_1X1 = 1,    // 1x1 / plain GEMM, no padding: one pointer bump per DMA, no bounds test
-       MODE_SMALLC = 2  // Cin == 4 (the stem on NHWC4 frames): one tap per 16-byte vector, per lane
+       MODE_DENSE = 2   // any Cin % 4 == 0 (the stem on NHWC4 frames, HRNet's 40/80-channel branches): K is the plain
+                        // (r, s, c) order over the REAL channels, so no k is spent on channel padding; every 16-byte
+                        // vector carries its own (tap, channel offset), derived per lane with two multiply-highs
 };
 
 // Epilogue staging: per pass every wave stages AS of its 32-row accumulator blocks, so a pass holds
@@ -94,7 +97,10 @@ constexpr int lds_floats(int BM, int BN, int WGM, int KB) {
 // T = _Float16 (BASELINE configs[4]): v_mfma_f32_32x32x16_f16 with fp32 accumulation, 8 elements per chunk,
 // KB = 64: the LDS image, the DMA pattern and the swizzle are byte-identical to the fp32 kernel; one
 // 16-byte chunk is exactly one MFMA operand (k = 8*kh + j), so a q-group is ONE MFMA per block pair.
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB>
+// PARTN = true (chosen when the last N-tile holds at least one all-padding 32-column block, e.g. Cout = 80 / 160 / 320
+// under 128- or 256-wide tiles): a wave skips the fragment reads and MFMAs of its all-padding blocks, and the waves are
+// mapped to sub-tiles so that the two waves sharing a SIMD cover complementary column ranges.
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p) {
     constexpr bool F16 = sizeof(T) == 2;
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
@@ -119,7 +125,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
-    const int wm = wave / WGN, wn = wave % WGN;
+    int wm = wave / WGN, wn = wave % WGN;
+    if constexpr (PARTN && NT == 512) {   // waves w and w + 4 share SIMD w & 3: give them different column ranges
+        if constexpr (WGN == 2) { wm = wave >> 1; wn = (wave ^ (wave >> 2)) & 1; }
+        if constexpr (WGN == 4) { wm = wave >> 2; wn = wm ? 3 - (wave & 3) : (wave & 3); }
+    }
     unsigned long long t_entry = 0;
     if (p.dbg) t_entry = __builtin_amdgcn_s_memrealtime();
 
@@ -178,6 +188,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+    int tnr = TN;   // 32-column blocks of this wave that hold at least one real output channel (wave-uniform)
+    if constexpr (PARTN) {
+        tnr = (p.Cout - (nt * BN + wn * WN) + 31) / 32;
+        tnr = __builtin_amdgcn_readfirstlane(tnr < 0 ? 0 : (tnr > TN ? TN : tnr));
+    }
     int cr = 0, cs = 0, cc = 0, cdelta = 0, ck = 0;   // load cursor (wave-uniform)
     const int nk = p.Kpad / KB;
 
@@ -185,11 +200,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
 #define HMV_DMA(buf)                                                                                        \
     {                                                                                                       \
         int sr_ = 0, ss_ = 0;                                                                               \
-        if (MODE == MODE_SMALLC) { /* lane-private tap of this 16-byte vector */                            \
-            const int tap_ = ck / EPC + kqs;                                                                \
-            sr_ = tap_ / p.S;                                                                               \
-            ss_ = tap_ - sr_ * p.S;                                                                         \
-            if (tap_ >= p.R * p.S) sr_ = 1 << 28;                                                           \
+        int sc_ = 0;                                                                                        \
+        if (MODE == MODE_DENSE) { /* lane-private (tap, channel offset) of this 16-byte vector */           \
+            const unsigned g_ = (unsigned)(ck / EPC + kqs);                                                 \
+            const unsigned tap_ = p.cpt == 1 ? g_ : __umulhi(g_, p.cpt_magic);   /* g / (Cin / EPC) */      \
+            sc_ = (int)(g_ - tap_ * (unsigned)p.cpt) * EPC;                                                 \
+            sr_ = p.S == 1 ? (int)tap_ : (int)__umulhi(tap_, p.s_magic);         /* tap / S */              \
+            ss_ = (int)tap_ - sr_ * p.S;                                                                    \
+            if (tap_ >= (unsigned)(p.R * p.S)) sr_ = 1 << 29;                                               \
         }                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                    \
             const T *src_;                                                                                  \
@@ -200,9 +218,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
                 const bool ok_ = (unsigned)(hi0[i] + cr) < (unsigned)p.H && (unsigned)(wi0[i] + cs) < (unsigned)p.W; \
                 src_ = ok_ ? aptr[i] + cdelta : zero;                                                       \
             } else {                                                                                        \
-                const int hi_ = hi0[i] + sr_, wi_ = wi0[i] + ss_;                                           \
+                const int hi_ = (hi0[i] + sr_) >> p.up, wi_ = (wi0[i] + ss_) >> p.up;                       \
                 const bool ok_ = (unsigned)hi_ < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.W;            \
-                src_ = ok_ ? aptr[i] + (hi_ * p.W + wi_) * p.lda : zero;                                    \
+                src_ = ok_ ? aptr[i] + (hi_ * p.W + wi_) * p.lda + sc_ : zero;                              \
             }                                                                                               \
             HMV_GLDS16(src_, sA + ((buf) * BM + i * RPS + wave * RPW) * KB);                                \
         }                                                                                                   \
@@ -233,21 +251,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     {                                                                                                       \
         const int ch_ = ((2 * (q) + kh) ^ fsw) * EPC;                                                       \
         _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                      \
-            FA[a] = *reinterpret_cast<const f32x4 *>(arow + ((buf) * BM + a * 32) * KB + ch_);              \
+            if (!PARTN || tnr > 0) FA[a] = *reinterpret_cast<const f32x4 *>(arow + ((buf) * BM + a * 32) * KB + ch_); \
         _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                      \
-            FB[b] = *reinterpret_cast<const f32x4 *>(brow + ((buf) * BN + b * 32) * KB + ch_);              \
+            if (!PARTN || b < tnr) FB[b] = *reinterpret_cast<const f32x4 *>(brow + ((buf) * BN + b * 32) * KB + ch_); \
     }
 #define HMV_MFMA(FA, FB)                                                                                    \
     {                                                                                                       \
         if constexpr (F16) {                                                                                \
             _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                  \
                 _Pragma("unroll") for (int b = 0; b < TN; ++b)                                              \
+                    if (!PARTN || b < tnr)                                                                  \
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, FA[a]),    \
                                                                        __builtin_bit_cast(f16x8, FB[b]), acc[a][b], 0, 0, 0); \
         } else {                                                                                            \
             _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                   \
                 _Pragma("unroll") for (int a = 0; a < TM; ++a)                                              \
                     _Pragma("unroll") for (int b = 0; b < TN; ++b)                                          \
+                        if (!PARTN || b < tnr)                                                              \
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a][e], FB[b][e], acc[a][b], 0, 0, 0); \
         }                                                                                                   \
     }
@@ -415,29 +435,41 @@ int conv_tile_bn(ConvTile t) {
 }
 
 // Family name = one rocprofv3 symbol: conv_igemm<T, BM, BN, WGM, WGN, MODE, false, KB>
-const char *conv_tile_name_f16(ConvTile t, int mode) {
-    static const char *names[TILE_COUNT][2] = {
-        {"conv_igemm_f16<128x32,taps>", "conv_igemm_f16<128x32,1x1>"},   {"conv_igemm_f16<128x64,taps>", "conv_igemm_f16<128x64,1x1>"},
-        {"conv_igemm_f16<128x128,taps>", "conv_igemm_f16<128x128,1x1>"}, {"conv_igemm_f16<256x128,taps>", "conv_igemm_f16<256x128,1x1>"},
-        {"conv_igemm_f16<128x256,taps>", "conv_igemm_f16<128x256,1x1>"}, {"conv_igemm_f16<256x256,taps>", "conv_igemm_f16<256x256,1x1>"},
-        {"conv_igemm_f16<128x128,taps>", "conv_igemm_f16<128x128,1x1>"}, {"conv_igemm_f16<128x256,taps>", "conv_igemm_f16<128x256,1x1>"},
-        {"conv_igemm_f16<256x128,taps>", "conv_igemm_f16<256x128,1x1>"}, {"conv_igemm_f16<64x64,taps>", "conv_igemm_f16<64x64,1x1>"}};
-    if (mode == 2) return "conv_igemm_f16<128x64,stem>";
-    if (t < 0 || t >= TILE_COUNT) return "conv_igemm_f16<?>";
-    return names[t][mode == 1 ? 1 : 0];
+static const char *kTileShape[TILE_COUNT] = {"128x32", "128x64", "128x128", "256x128", "128x256", "256x256", "128x128,k16",
+                                              "128x256,k16", "256x128,k16", "64x64"};
+static const char *tile_name(const char *dtype, ConvTile t, int mode, bool partn = false) {
+    static char names[2][TILE_COUNT][3][2][56];
+    if (t < 0 || t >= TILE_COUNT || mode < 0 || mode > 2) return "conv_igemm<?>";
+    const int d = dtype[1] == '1';   // "f16" / "f32"
+    char *n = names[d][t][mode][partn ? 1 : 0];
+    if (!n[0])
+        snprintf(n, sizeof(names[0][0][0][0]), "conv_igemm_%s<%s,%s%s>", dtype, kTileShape[t],
+                 mode == 0 ? "taps" : (mode == 1 ? "1x1" : "dense"), partn ? ",skipN" : "");
+    return n;
 }
-const char *conv_tile_name(ConvTile t, int mode) {
-    static const char *names[TILE_COUNT][2] = {
-        {"conv_igemm_f32<128x32,taps>", "conv_igemm_f32<128x32,1x1>"},   {"conv_igemm_f32<128x64,taps>", "conv_igemm_f32<128x64,1x1>"},
-        {"conv_igemm_f32<128x128,taps>", "conv_igemm_f32<128x128,1x1>"}, {"conv_igemm_f32<256x128,taps>", "conv_igemm_f32<256x128,1x1>"},
-        {"conv_igemm_f32<128x256,taps>", "conv_igemm_f32<128x256,1x1>"}, {"conv_igemm_f32<256x256,taps>", "conv_igemm_f32<256x256,1x1>"},
-        {"conv_igemm_f32<128x128,k16,taps>", "conv_igemm_f32<128x128,k16,1x1>"},
-        {"conv_igemm_f32<128x256,k16,taps>", "conv_igemm_f32<128x256,k16,1x1>"},
-        {"conv_igemm_f32<256x128,k16,taps>", "conv_igemm_f32<256x128,k16,1x1>"},
-        {"conv_igemm_f32<64x64,taps>", "conv_igemm_f32<64x64,1x1>"}};
-    if (mode == 2) return "conv_igemm_f32<128x64,stem>";
-    if (t < 0 || t >= TILE_COUNT) return "conv_igemm_f32<?>";
-    return names[t][mode == 1 ? 1 : 0];
+// fp16 has no half-step variants of the big tiles: they run as their full-step tile
+const char *conv_tile_name_f16(ConvTile t, int mode) {
+    if (t == TILE_128x256_K16) t = TILE_128x256;
+    if (t == TILE_256x128_K16) t = TILE_256x128;
+    if (t == TILE_128x128_K16) t = TILE_128x128;
+    return tile_name("f16", t, mode);
+}
+const char *conv_tile_name(ConvTile t, int mode) { return tile_name("f32", t, mode); }
+
+// the tile a dense-K launch really uses (fewer instantiations than the chunked modes)
+ConvTile conv_dense_tile(ConvTile t, bool f16) {
+    if (f16) return t == TILE_128x32 ? TILE_128x32 : TILE_128x64;
+    switch (t) {
+        case TILE_128x32: case TILE_128x64: case TILE_64x64: case TILE_256x128: return t;
+        case TILE_256x128_K16: case TILE_256x256: return TILE_256x128;
+        default: return TILE_128x128;
+    }
+}
+// true when the tile has a block-skipping instantiation and the last N-tile has an all-padding 32-column block
+bool conv_partial_n(ConvTile t, int Cout) {
+    if (t != TILE_128x128 && t != TILE_256x128 && t != TILE_256x256) return false;
+    const int bn = conv_tile_bn(t);
+    return (Cout + bn - 1) / bn * bn - Cout >= 32;
 }
 
 ConvTile conv_pick_tile(int M, int Cout, int K) {
@@ -449,6 +481,11 @@ ConvTile conv_pick_tile(int M, int Cout, int K) {
     // tiny-K expanding convs (layer1/2 conv3 + residual) are epilogue/HBM-bound: 4 small blocks per CU
     // overlap one block's residual read / store with the others' short main loops
     if (Cout >= 256 && K <= 128 && M >= 65536) return TILE_128x128_K16;
+    // channel counts that are not multiples of 128 (HRNet-w40: 160, 320), measured with tools/hr_sweep.py: one 256-wide
+    // N-tile with its all-padding blocks skipped beats two 128-wide tiles whose second one is mostly DMA latency;
+    // 64-wide tiles beat 128-wide ones when the last 128-wide tile would be at most half real.
+    if (Cout > 128 && Cout <= 192 && M >= 16384) return (M + 255) / 256 >= 256 ? TILE_256x256 : TILE_128x64;
+    if (Cout > 256 && M >= 16384 && Cout % 128 != 0 && Cout % 128 <= 64) return TILE_128x64;
     if (Cout > 128 && (long long)((M + 255) / 256) * ((Cout + 255) / 256) >= 512) return TILE_256x256;
     if (Cout > 64 && (long long)((M + 255) / 256) * ((Cout + 127) / 128) >= 512) return TILE_256x128;
     // small problems (few frames, or the token GEMMs of the fusion transformer): 64x64 tiles give 4x the
@@ -459,11 +496,11 @@ ConvTile conv_pick_tile(int M, int Cout, int K) {
     return TILE_128x32;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false>
 static hipError_t launch_one(ConvParams p, hipStream_t s) {
     static bool configured = false;
     const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4) * sizeof(float);
-    auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB>;
+    auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -486,7 +523,8 @@ static hipError_t launch_plain(const ConvParams &p, bool one, hipStream_t s) {
     return one ? launch_one<T, BM, BN, WGM, WGN, MODE_1X1, false, KB>(p, s) : launch_one<T, BM, BN, WGM, WGN, MODE_TAPS, false, KB>(p, s);
 }
 
-hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s) {
+hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **name) {
+    if (name) *name = "conv_igemm<none>";
     if (p.M <= 0) return hipSuccess;
     {
         hipError_t e = ensure_zero_page();
@@ -501,12 +539,50 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s) {
     if (generic && (tile == TILE_256x128 || tile == TILE_128x256 || tile == TILE_256x256 || tile == TILE_128x128_K16 ||
                     tile == TILE_128x256_K16 || tile == TILE_256x128_K16))
         tile = TILE_128x128;   // the rarely used epilogue paths exist only for the 4-wave tiles
-    if (p.in_f16) {   // fp16 operands (k-step 64); the half-step variants map to their full-step tile
-        if (p.Cin < 64) {   // stem: NHWC8 frames
-            if (p.Cin != 8 || generic) return hipErrorInvalidValue;
-            return launch_one<_Float16, 128, 64, 2, 2, MODE_SMALLC, false, 64>(p, s);
+    const int ch = p.in_f16 ? 64 : 32, epc = p.in_f16 ? 8 : 4;
+    const bool dense = p.Cin % ch != 0;
+    if (dense) {
+        if (p.Cin % epc != 0 || p.lda % epc != 0 || generic || p.Kpad > (1 << 16)) return hipErrorInvalidValue;
+        p.cpt = p.Cin / epc;
+        p.cpt_magic = p.cpt > 1 ? (unsigned)(0xFFFFFFFFu / (unsigned)p.cpt) + 1u : 0u;
+        p.s_magic = p.S > 1 ? (unsigned)(0xFFFFFFFFu / (unsigned)p.S) + 1u : 0u;
+        if (p.up && (p.R != 1 || p.S != 1 || p.pad_h || p.pad_w || p.stride != 1)) return hipErrorInvalidValue;
+        tile = conv_dense_tile(tile, p.in_f16 != 0);
+    }
+    // last N-tile with >= 32 all-padding columns: the block-skipping instantiations (fp32, the three big tiles)
+    const int mode = dense ? MODE_DENSE : (one ? MODE_1X1 : MODE_TAPS);
+    static int no_skip = -1;   // development knob: HMV_NO_SKIPN=1 disables the block-skipping instantiations (A/B runs)
+    if (no_skip < 0) { const char *e = getenv("HMV_NO_SKIPN"); no_skip = e ? atoi(e) : 0; }
+    const bool partn = !no_skip && !p.in_f16 && !generic && conv_partial_n(tile, p.Cout) && !(dense && tile == TILE_256x256);
+    if (name) *name = p.in_f16 ? conv_tile_name_f16(tile, mode) : tile_name("f32", tile, mode, partn);
+    if (partn) {
+#define HMV_PARTN(BM_, BN_, WGM_, WGN_)                                                                              \
+        switch (mode) {                                                                                                 \
+            case MODE_DENSE: return launch_one<float, BM_, BN_, WGM_, WGN_, MODE_DENSE, false, 32, true>(p, s);         \
+            case MODE_1X1: return launch_one<float, BM_, BN_, WGM_, WGN_, MODE_1X1, false, 32, true>(p, s);             \
+            default: return launch_one<float, BM_, BN_, WGM_, WGN_, MODE_TAPS, false, 32, true>(p, s);                  \
         }
-        if (p.Cin % 64 != 0 || p.Kpad % 64 != 0) return hipErrorInvalidValue;
+        if (tile == TILE_128x128) { HMV_PARTN(128, 128, 2, 2) }
+        if (tile == TILE_256x128) { HMV_PARTN(256, 128, 4, 2) }
+        if (tile == TILE_256x256) { HMV_PARTN(256, 256, 2, 4) }
+#undef HMV_PARTN
+    }
+    if (dense) {   // dense K order over the real channels (stem, HRNet's 40 / 80-channel tensors)
+        if (p.in_f16) {
+            switch (tile) {
+                case TILE_128x32: return launch_one<_Float16, 128, 32, 4, 1, MODE_DENSE, false, 64>(p, s);
+                default: return launch_one<_Float16, 128, 64, 2, 2, MODE_DENSE, false, 64>(p, s);
+            }
+        }
+        switch (tile) {
+            case TILE_128x32: return launch_one<float, 128, 32, 4, 1, MODE_DENSE, false, 32>(p, s);
+            case TILE_128x64: return launch_one<float, 128, 64, 2, 2, MODE_DENSE, false, 32>(p, s);
+            case TILE_64x64: return launch_one<float, 64, 64, 2, 2, MODE_DENSE, false, 32>(p, s);
+            case TILE_256x128: return launch_one<float, 256, 128, 4, 2, MODE_DENSE, false, 32>(p, s);
+            default: return launch_one<float, 128, 128, 2, 2, MODE_DENSE, false, 32>(p, s);
+        }
+    }
+    if (p.in_f16) {   // fp16 operands (k-step 64); the half-step variants map to their full-step tile
         switch (tile) {
             case TILE_128x32: return launch_modes<_Float16, 128, 32, 4, 1, 64>(p, one, generic, s);
             case TILE_128x64: return launch_modes<_Float16, 128, 64, 2, 2, 64>(p, one, generic, s);
@@ -519,11 +595,6 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s) {
             default: return hipErrorInvalidValue;
         }
     }
-    if (p.Cin < BK) {  // stem: NHWC4 frames
-        if (p.Cin != 4 || generic) return hipErrorInvalidValue;
-        return launch_one<float, 128, 64, 2, 2, MODE_SMALLC, false, 32>(p, s);
-    }
-    if (p.Cin % BK != 0) return hipErrorInvalidValue;
     switch (tile) {
         case TILE_128x32: return launch_modes<float, 128, 32, 4, 1, 32>(p, one, generic, s);
         case TILE_128x64: return launch_modes<float, 128, 64, 2, 2, 32>(p, one, generic, s);

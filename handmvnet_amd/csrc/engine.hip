@@ -27,7 +27,7 @@ namespace {
 constexpr int NJ = 21, HEADS = 8, DHEAD = 128, INNER = HEADS * DHEAD;
 const int kBlocks[3][4] = {{2, 2, 2, 2}, {3, 4, 6, 3}, {3, 4, 6, 3}};
 const int kHrChannels[2][4] = {{40, 80, 160, 320}, {64, 128, 256, 512}};   // hrnet.py:430-447
-inline int cpad(int c) { return (c + 31) / 32 * 32; }                      // padded NHWC channel stride
+inline int cpad(int c) { return (c + 3) / 4 * 4; }   // NHWC channel stride: 16-byte pixels are all the conv kernel needs
 
 std::string g_create_err;
 
@@ -305,12 +305,12 @@ struct Loader {
         const float *wd = w->data.data();
         auto wt = [=](int o, int k) -> float {
             int c, tap;
-            if (cp >= 32) {   // K order (chunk, r, s, c % CH), CH = 32 (fp32) / 64 (fp16): conv_igemm.hip
-                const int CH = f16 ? 64 : 32;
+            const int CH = f16 ? 64 : 32;
+            if (cp % CH == 0) {   // K order (chunk, r, s, c % CH), CH = 32 (fp32) / 64 (fp16): conv_igemm.hip
                 const int chunk = k / (CH * R * S), rem = k % (CH * R * S);
                 tap = rem / CH;
                 c = chunk * CH + rem % CH;
-            } else {          // the stem: (r, s, c)
+            } else {          // dense K order (r, s, c) over the real channels: the stem, HRNet's 40 / 80-channel tensors
                 c = k % cp;
                 tap = k / cp;
             }
@@ -781,16 +781,18 @@ struct Runner {
                 h->prof.push_back(r);
             }
             pr = &h->prof[h->prof_used++];
-            const int mode_ = L.Cin < 32 ? 2 : ((L.R == 1 && L.S == 1 && pad_h == 0 && pad_w == 0) ? 1 : 0);
-            pr->name = L.f16 ? conv_tile_name_f16(tile, mode_) : conv_tile_name(tile, mode_);
             pr->label = L.label;
             // algorithmic FLOPs: the real (un-padded) reduction length; the stem's 4th channel is padding
             const double kreal = L.Kreal ? (double)L.Kreal : (double)L.K;   // real channels only (no padding FLOPs)
             pr->flops = 2.0 * (double)p.M * (double)L.Cout * kreal;
             check(hipEventRecord(pr->e0, s), "hipEventRecord");
         }
-        check(launch_conv(p, tile, s), L.label.c_str());
-        if (pr) check(hipEventRecord(pr->e1, s), "hipEventRecord");
+        const char *kname = nullptr;
+        check(launch_conv(p, tile, s, &kname), L.label.c_str());
+        if (pr) {
+            pr->name = kname;
+            check(hipEventRecord(pr->e1, s), "hipEventRecord");
+        }
     }
 
     void gemm(const Layer &L, const float *a, int rows, float *out, int ldc, const float *res, int ldr, int act, int rg_out = 0,
@@ -1319,8 +1321,8 @@ int hmv_profile_get(hmv_handle h, int32_t index, const char **name, const char *
 int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *w_oihw,
                   const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad, const float *residual,
                   int32_t relu, float *out, void *stream) {
-    if (!in || !w_oihw || !out || Cin % 4 != 0 || (Cin >= 32 && Cin % 32 != 0) || (Cin < 32 && Cin != 4)) {
-        g_create_err = "hmv_op_conv2d: Cin must be 4 or a multiple of 32";
+    if (!in || !w_oihw || !out || Cin % 4 != 0) {
+        g_create_err = "hmv_op_conv2d: Cin must be a multiple of 4";
         return HMV_ERR_ARG;
     }
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
@@ -1329,7 +1331,7 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
     for (int o = 0; o < Cout; ++o) {
         for (int k = 0; k < K; ++k) {
             int c, tap;
-            if (Cin >= 32) { const int chunk = k / (32 * R * S), rem = k % (32 * R * S); tap = rem / 32; c = chunk * 32 + rem % 32; }
+            if (Cin % 32 == 0) { const int chunk = k / (32 * R * S), rem = k % (32 * R * S); tap = rem / 32; c = chunk * 32 + rem % 32; }
             else { c = k % Cin; tap = k / Cin; }
             w[(size_t)o * Kpad + k] = w_oihw[(((size_t)o * Cin + c) * R + tap / S) * S + tap % S];
         }

@@ -19,7 +19,7 @@ struct ConvParams {
     const void *res;    // residual, row-major [M'][ldr] or null; fp16 if res_f16
     void *out;          // [M''][ldc]; fp16 if out_f16
     int in_f16, res_f16, out_f16;
-    int up;             // 1x1 mode only: output pixel (ho, wo) reads input pixel (ho >> up, wo >> up) -- a 1x1 conv
+    int up;             // 1x1 and dense modes (R = S = 1, no padding) only: output pixel (ho, wo) reads input pixel (ho >> up, wo >> up) -- a 1x1 conv
                         // commutes with nearest-neighbour upsampling (HRNet fuse layers); H, W are the INPUT dims
     int fill;           // write columns [Cout, ldc) too (exact zeros): keeps padded channel strides clean
     int N, H, W, Cin;
@@ -34,6 +34,8 @@ struct ConvParams {
     int osy, osx, ooy, oox;
     int mtiles, ntiles;
     const float *zero;  // 256 bytes of zeros (filled in by launch_conv)
+    int cpt;            // dense mode: 16-byte vectors per tap (Cin / 4, or Cin / 8 in fp16); filled in by launch_conv
+    unsigned cpt_magic, s_magic;   // ceil(2^32 / cpt), ceil(2^32 / S): exact division by multiply-high for k indices < 2^16
     int lda;            // input pixel stride in floats (0 = Cin)
     int ldw;            // weight row stride in floats (0 = Kpad)
     unsigned long long *dbg;  // diagnostic builds only: per-block {shader cycles, 100 MHz ticks} of the main loop
@@ -42,11 +44,14 @@ struct ConvParams {
 enum ConvTile { TILE_128x32 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x128 = 3, TILE_128x256 = 4, TILE_256x256 = 5,
                 TILE_128x128_K16 = 6, TILE_128x256_K16 = 7, TILE_256x128_K16 = 8, TILE_64x64 = 9, TILE_COUNT = 10 };
 int conv_tile_bn(ConvTile t);                       // N-tile width of a tile config
-const char *conv_tile_name(ConvTile t, int mode);   // mode: 0 taps, 1 1x1/GEMM, 2 stem
+const char *conv_tile_name(ConvTile t, int mode);   // mode: 0 taps, 1 1x1/GEMM, 2 dense K (stem, Cin % 32 != 0)
 const char *conv_tile_name_f16(ConvTile t, int mode);
 ConvTile conv_pick_tile(int M, int Cout, int K);
+ConvTile conv_dense_tile(ConvTile t, bool f16);     // the tile a dense-K (Cin % 32 != 0) launch really uses
+bool conv_partial_n(ConvTile t, int Cout);          // launch_conv uses the block-skipping instantiation
 // fills mtiles/ntiles and launches
-hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s);
+// `name` (optional) receives the kernel family actually launched ("conv_igemm_f32<256x128,dense,skipN>" ...)
+hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **name = nullptr);
 
 // ---- small kernels
 hipError_t launch_nchw_to_nhwc4(const float *x, float *out, int N, int H, int W, hipStream_t s);

@@ -93,6 +93,18 @@ CONV_SHAPES = [
     (1, 8, 8, 512, 21, 1, 1, 0, False, False),
     (3, 32, 32, 4, 64, 7, 2, 3, False, True),       # the stem: NHWC4 frames
     (1, 9, 7, 32, 160, 3, 1, 1, True, False),        # ragged M and N tails
+    # dense K order over the real channels (Cin % 32 != 0: HRNet's 40 / 80-channel tensors)
+    (2, 16, 16, 40, 40, 3, 1, 1, True, True),
+    (1, 16, 16, 80, 80, 3, 1, 1, False, True),
+    (2, 16, 16, 40, 80, 3, 2, 1, False, False),
+    (1, 16, 16, 80, 40, 1, 1, 0, False, False),
+    (1, 9, 7, 12, 20, 3, 1, 1, True, True),           # 3 vectors per tap, ragged everything
+    (32, 64, 64, 80, 80, 3, 1, 1, True, True),        # 256x128 dense, last 32-column block skipped
+    # block skipping in the chunked modes (Cout = 160 / 320 under 128- and 256-wide tiles)
+    (8, 64, 64, 160, 160, 3, 1, 1, False, True),      # 128x128 taps
+    (32, 32, 32, 96, 160, 1, 1, 0, True, False),      # 128x128 1x1
+    (16, 64, 64, 64, 320, 1, 1, 0, False, True),      # 256x256 1x1
+    (32, 64, 64, 32, 160, 3, 1, 1, True, True),       # 256x256 taps
 ]
 
 

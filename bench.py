@@ -107,6 +107,11 @@ def main():
     ap.add_argument("--input", default="nchw", choices=["nchw", "frames"],
                     help="nchw = prepared fp32 batch (eval_fps.py protocol, the headline); frames = raw uint8 480x640 camera "
                          "frames + crop windows through hmv_forward_frames (SURVEY 8(f) row 4)")
+    ap.add_argument("--instrument-every", type=int, default=4,
+                    help="bracket every conv/GEMM launch with a hipEvent pair on every Nth timed step (N=1: every step; the "
+                         "events cost ~0.5 ms per instrumented cfg-3 step); 0: none in the timed region, roofline from a "
+                         "separate instrumented pass afterwards")
+    ap.add_argument("--graphs", action="store_true", help="opt into hipGraph replay for the un-instrumented steps")
     ap.add_argument("--per-layer", default="", help="write per-layer launch timings (JSON) to this file")
     args = ap.parse_args()
 
@@ -161,17 +166,35 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    model.set_profiling(True)          # hipEvent pairs around every conv/GEMM launch of the timed steps
+    if args.graphs:
+        model.use_graphs(True)
+    every = args.instrument_every
+    model.set_profiling(True)          # fresh record list ...
+    model.set_profiling(False)         # ... paused until an instrumented step resumes it
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    n_instr = 0
+    for i in range(args.steps):
+        instr = every > 0 and i % every == 0
+        if instr:                      # hipEvent pairs around every conv/GEMM launch of this timed step
+            model.set_profiling(2)
+            n_instr += 1
         step()
+        if instr:
+            model.set_profiling(False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    graph_stats = model.graph_stats()
+    if n_instr == 0:                   # the roofline pass: same K steps, instrumented, not part of `value`
+        model.set_profiling(2)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        n_instr = args.steps
     recs = model.profile_records()
     model.set_profiling(False)
     if world > 1:
@@ -209,12 +232,12 @@ def main():
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                    "launches_per_step": d["n"] // max(args.steps, 1), "avg_launch_ms": round(d["ms"] / d["n"], 4),
+                    "launches_per_step": d["n"] // max(n_instr, 1), "avg_launch_ms": round(d["ms"] / d["n"], 4),
                     "flops_per_launch": d["flops"] / d["n"]}
         ms_step = elapsed / args.steps * 1e3
         # dense algorithmic count for the ResNet workloads; for HRNet the executed FLOPs of the
         # conv/GEMM launches of one step (the engine's own 2*M*N*K accounting)
-        total_flops = sum(r["flops"] for r in recs) / max(args.steps, 1) if cfg.is_hrnet else forward_flops(cfg, B, size)
+        total_flops = sum(r["flops"] for r in recs) / max(n_instr, 1) if cfg.is_hrnet else forward_flops(cfg, B, size)
         line = {
             "metric": "samples/sec (BxV frames) eval_fps.py, 8-view 256x256; 21-kpt L2 vs reference",
             "value": round(args.steps * B * V * world / elapsed, 2), "unit": "frames/s", "n_gpus": world,
@@ -225,10 +248,14 @@ def main():
                                    f"{'hrnet_' if cfg.is_hrnet else 'resnet'}{bt} backbone, d={cfg.feat_dim}, cross_attn x{cfg.fusion_layers}, GCN decoder",
                        "global_batch": B * world, "views": V, "frame": size, "parallelism": f"sample-shard x{world}"},
             "roofline": roofline,
+            "timed_region": {"instrumented_steps": n_instr if every > 0 else 0,
+                             "note": "hipEvent pair around every conv/GEMM launch on the instrumented steps" if every > 0
+                                     else "no events in the timed region; roofline from a separate instrumented pass of the same steps",
+                             "hipgraph": {"enabled": bool(args.graphs), "cached": graph_stats[0], "replays": graph_stats[1]}},
             "forward": {"algorithmic_gflop": round(total_flops / 1e9, 1),
                         "tflops": round(total_flops / (ms_step * 1e-3) / 1e12, 2),
                         "frac_of_f32_mfma_peak": round(total_flops / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
-            "kernels": {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+            "kernels": {k: {"ms_per_step": round(v["ms"] / n_instr, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                         for k, v in fam.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("HMV_LIB") or os.path.join(_HERE, "libhandmv.so")   # 
 SYMBOLS = ["hmv_create", "hmv_set_tensor", "hmv_finalize_weights", "hmv_workspace_bytes", "hmv_reserve", "hmv_forward",
            "hmv_last_error", "hmv_destroy", "hmv_set_capture", "hmv_read_stage", "hmv_set_profiling", "hmv_profile_count",
            "hmv_profile_get", "hmv_op_conv2d", "hmv_bench_conv", "hmv_pose_metrics", "hmv_forward_frames",
-           "hmv_op_prepare_frames", "hmv_version"]
+           "hmv_op_prepare_frames", "hmv_set_graphs", "hmv_graph_stats", "hmv_version"]
 
 HMV_OK = 0
 
@@ -70,6 +70,10 @@ def load() -> ctypes.CDLL:
     lib.hmv_op_prepare_frames.argtypes = [ci, fp, ci, ci, ci, fp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                           ci, ci, fp, vp]
     lib.hmv_op_prepare_frames.restype = ctypes.c_int
+    lib.hmv_set_graphs.argtypes = [vp, ci]
+    lib.hmv_set_graphs.restype = ctypes.c_int
+    lib.hmv_graph_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]
+    lib.hmv_graph_stats.restype = ctypes.c_int
     lib.hmv_version.restype = ctypes.c_char_p
     for name in ("hmv_create", "hmv_set_tensor", "hmv_finalize_weights", "hmv_reserve", "hmv_forward", "hmv_set_capture",
                  "hmv_read_stage", "hmv_set_profiling", "hmv_profile_count", "hmv_profile_get", "hmv_op_conv2d"):

@@ -54,6 +54,7 @@ class HandMvNet(torch.nn.Module):
         self._dtype = 0   # 0 = fp32 (HMV_F32), 1 = fp16 conv stack (HMV_F16, BASELINE configs[4])
         self._capture = False
         self._profiling = False
+        self._graphs = None   # None: the engine's default (off unless HMV_GRAPHS=1)
         self._last_key: Optional[tuple] = None
 
     # ------------------------------------------------------------------ Lightning-style protocol
@@ -144,6 +145,8 @@ class HandMvNet(torch.nn.Module):
             _lib.check(lib.hmv_finalize_weights(h), h)
             lib.hmv_set_capture(h, int(self._capture))
             lib.hmv_set_profiling(h, int(self._profiling))
+            if self._graphs is not None:
+                lib.hmv_set_graphs(h, int(self._graphs))
         except Exception:
             lib.hmv_destroy(h)
             raise
@@ -294,7 +297,21 @@ class HandMvNet(torch.nn.Module):
         _lib.check(_lib.load().hmv_read_stage(h, name.encode(), out.data_ptr(), out.numel(), ctypes.c_void_p(stream)), h)
         return out
 
-    def set_profiling(self, enable: bool = True):
+    def use_graphs(self, enable: bool = True):
+        """hipGraph replay of repeated forwards (opt-in, see include/handmv.h: hmv_set_graphs)."""
+        self._graphs = bool(enable)
+        for h in self._engines.values():
+            _lib.load().hmv_set_graphs(h, int(enable))
+
+    def graph_stats(self):
+        """(graphs cached, replays so far) of the engine the last forward ran on."""
+        hh, ww, idx, _, dt = self._last_key
+        cached, replays = ctypes.c_int32(), ctypes.c_int64()
+        _lib.check(_lib.load().hmv_graph_stats(self._engines[(hh, ww, idx, dt)], ctypes.byref(cached), ctypes.byref(replays)))
+        return cached.value, replays.value
+
+    def set_profiling(self, enable=True):
+        """True / 1: start a fresh record list; False / 0: pause (records kept); 2: resume without clearing."""
         self._profiling = bool(enable)
         for h in self._engines.values():
             _lib.load().hmv_set_profiling(h, int(enable))

@@ -106,7 +106,8 @@ int hmv_read_stage(hmv_handle h, const char *stage, float *dst_device, size_t ca
 /* Per-launch timing with hipEvents on the forward's stream (0 = off, 1 = on).  When on,
  * hmv_forward records an event pair around every kernel launch of the conv/GEMM kernel
  * family; records accumulate over successive forwards (calling hmv_set_profiling again
- * clears them); hmv_profile_* read them back after the caller has synchronised the stream. */
+ * clears them; enable = 0 pauses and keeps the records, enable = 2 resumes without clearing);
+ * hmv_profile_* read them back after the caller has synchronised the stream. */
 int hmv_set_profiling(hmv_handle h, int32_t enable);
 int hmv_profile_count(hmv_handle h);
 /* name: kernel family = one device symbol ("conv_igemm_f32<256x256,1x1>" ...); label: layer ("layer3.2.conv2");
@@ -125,6 +126,15 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
  * 128x256, 256x256, 128x128 (k-step 16), 128x256 (k-step 16) (BM x BN).  HMV_BENCH_CLOCK=1 adds in-kernel clock stamps (stderr). */
 int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t R, int32_t S,
                    int32_t stride, int32_t pad, int32_t with_residual, int32_t tile, int32_t iters, float *avg_ms);
+
+/* hipGraph replay (opt-in: hmv_set_graphs(h, 1) or HMV_GRAPHS=1 in the environment; it saves host time per forward,
+ * not GPU time -- measured throughput on MI355X is the same as eager launches).
+ * A forward whose batch and caller buffers (x / frames, bbox, intrinsic and the three outputs) equal those of an
+ * earlier call is captured into a hipGraph on its second occurrence and replayed as ONE launch afterwards
+ * (up to 8 buffer sets per handle, least recently used evicted).  Results are bit-identical to the eager path;
+ * stage capture and profiling force the eager path.  hmv_graph_stats reports cached graphs / replays so far. */
+int hmv_set_graphs(hmv_handle h, int32_t enable);
+int hmv_graph_stats(hmv_handle h, int32_t *cached, int64_t *replays);
 
 /* hmv_forward from raw camera frames: the reference prepares every view on DataLoader workers
  * (datasets/ho3d.py:35-40, 136-149: crop_and_pad_image (datasets/utils.py:40-77) -> ToTensor -> Resize((S,S), antialias=True)

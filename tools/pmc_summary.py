@@ -25,11 +25,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def family(name: str) -> str:
     """rocprofv3 symbol -> the kernel family name bench.py / the engine use (one symbol per family)."""
-    m = re.match(r"void hmv::conv_igemm<(float|_Float16), (\d+), (\d+), \d+, \d+, (\d), (?:false|true), (\d+)>", name)
+    m = re.match(r"void hmv::conv_igemm<(float|_Float16), (\d+), (\d+), \d+, \d+, (\d), (?:false|true), (\d+)(?:, (false|true))?>", name)
     if m:
         t = "f32" if m.group(1) == "float" else "f16"
         k16 = ",k16" if (t == "f32" and m.group(5) == "16") else ""
-        return f"conv_igemm_{t}<{m.group(2)}x{m.group(3)}{k16}," + {"0": "taps", "1": "1x1", "2": "stem"}[m.group(4)] + ">"
+        skip = ",skipN" if m.group(6) == "true" else ""
+        return f"conv_igemm_{t}<{m.group(2)}x{m.group(3)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense"}[m.group(4)] + skip + ">"
     return re.sub(r"\(.*", "", name).replace("void ", "").replace("hmv::", "")
 
 

@@ -458,7 +458,6 @@ const char *conv_tile_name(ConvTile t, int mode) { return tile_name("f32", t, mo
 
 // the tile a dense-K launch really uses (fewer instantiations than the chunked modes)
 ConvTile conv_dense_tile(ConvTile t, bool f16) {
-    if (f16) return t == TILE_128x32 ? TILE_128x32 : TILE_128x64;
     switch (t) {
         case TILE_128x32: case TILE_128x64: case TILE_64x64: case TILE_256x128: return t;
         case TILE_256x128_K16: case TILE_256x256: return TILE_256x128;
@@ -472,7 +471,7 @@ bool conv_partial_n(ConvTile t, int Cout) {
     return (Cout + bn - 1) / bn * bn - Cout >= 32;
 }
 
-ConvTile conv_pick_tile(int M, int Cout, int K) {
+ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
     static int forced = -2;   // development knob: HMV_FORCE_TILE=<ConvTile> for layers with Cout > 64
     if (forced == -2) { const char *e = getenv("HMV_FORCE_TILE"); forced = e ? atoi(e) : -1; }
     if (Cout > 64 && forced >= 0 && forced < TILE_COUNT) return (ConvTile)forced;
@@ -481,6 +480,10 @@ ConvTile conv_pick_tile(int M, int Cout, int K) {
     // tiny-K expanding convs (layer1/2 conv3 + residual) are epilogue/HBM-bound: 4 small blocks per CU
     // overlap one block's residual read / store with the others' short main loops
     if (Cout >= 256 && K <= 128 && M >= 65536) return TILE_128x128_K16;
+    // fp16: the main loop of a residual-bearing expanding 1x1 conv is so short (K = 256: 4 k-steps) that the single
+    // 256x256 block per CU spends 3/4 of its life in the epilogue; 4 small blocks per CU overlap it (0.61 -> 0.47 ms on
+    // layer3 conv3, forced-tile A/B runs of bench.py --dtype f16 --per-layer)
+    if (f16 && has_res && Cout >= 256 && K <= 256 && M >= 65536) return TILE_128x128_K16;
     // channel counts that are not multiples of 128 (HRNet-w40: 160, 320), measured with tools/hr_sweep.py: one 256-wide
     // N-tile with its all-padding blocks skipped beats two 128-wide tiles whose second one is mostly DMA latency;
     // 64-wide tiles beat 128-wide ones when the last 128-wide tile would be at most half real.
@@ -571,7 +574,10 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         if (p.in_f16) {
             switch (tile) {
                 case TILE_128x32: return launch_one<_Float16, 128, 32, 4, 1, MODE_DENSE, false, 64>(p, s);
-                default: return launch_one<_Float16, 128, 64, 2, 2, MODE_DENSE, false, 64>(p, s);
+                case TILE_128x64: return launch_one<_Float16, 128, 64, 2, 2, MODE_DENSE, false, 64>(p, s);
+                case TILE_64x64: return launch_one<_Float16, 64, 64, 2, 2, MODE_DENSE, false, 64>(p, s);
+                case TILE_256x128: return launch_one<_Float16, 256, 128, 4, 2, MODE_DENSE, false, 64>(p, s);
+                default: return launch_one<_Float16, 128, 128, 2, 2, MODE_DENSE, false, 64>(p, s);
             }
         }
         switch (tile) {

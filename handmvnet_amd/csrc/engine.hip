@@ -386,7 +386,6 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     for (int i = 0; i < cfg->n_levels; ++i)
         if (cfg->channels[i] != (hrnet ? kHrChannels[cfg->backbone - HMV_HRNET_W40][i] : backbone_level_channels(*cfg, 2 - i)))
             return bad("backbone_channels do not match the backbone");
-    if (hrnet && cfg->dtype != HMV_F32) { g_create_err = "the fp16 path is built for the ResNet backbones only"; return HMV_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g_create_err = "no HIP device: libhandmv has no CPU fallback";
@@ -430,21 +429,21 @@ int hmv_finalize_weights(hmv_handle h) {
     const bool h16 = c.dtype == HMV_F16;   // conv stack in fp16; heat-map logits, tokens, fusion, decoder stay fp32
 
     if (h->hrnet) {
-        // ---- HighResolutionNet: hrnet.py:231-311.  Branch widths 40 / 80 are stored with padded strides 64 / 96.
+        // ---- HighResolutionNet: hrnet.py:231-311.  Every tensor keeps its real channel stride (dense-K conv mode for 40 / 80 channels).
         HrNet &hr = h->hr;
         hr = HrNet();
         for (int i = 0; i < 4; ++i) hr.ch[i] = kHrChannels[c.backbone - HMV_HRNET_W40][i];
-        L.conv(hr.conv1, "stem.conv1", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 3, 3, /*cin_pad=*/4);
-        L.conv(hr.conv2, "stem.conv2", "backbone.conv2.weight", "", "backbone.bn2", 64, 64, 3, 3);
+        L.conv(hr.conv1, "stem.conv1", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 3, 3, /*cin_pad=*/h16 ? 8 : 4, h16);
+        L.conv(hr.conv2, "stem.conv2", "backbone.conv2.weight", "", "backbone.bn2", 64, 64, 3, 3, 0, h16);
         int inpl_ = 64;
         for (int bi = 0; bi < 4; ++bi) {
             Block b;
             const std::string p = "backbone.layer1." + std::to_string(bi), lab = "layer1." + std::to_string(bi);
-            L.conv(b.c1, lab + ".conv1", p + ".conv1.weight", "", p + ".bn1", 64, inpl_, 1, 1);
-            L.conv(b.c2, lab + ".conv2", p + ".conv2.weight", "", p + ".bn2", 64, 64, 3, 3);
-            L.conv(b.c3, lab + ".conv3", p + ".conv3.weight", "", p + ".bn3", 256, 64, 1, 1);
+            L.conv(b.c1, lab + ".conv1", p + ".conv1.weight", "", p + ".bn1", 64, inpl_, 1, 1, 0, h16);
+            L.conv(b.c2, lab + ".conv2", p + ".conv2.weight", "", p + ".bn2", 64, 64, 3, 3, 0, h16);
+            L.conv(b.c3, lab + ".conv3", p + ".conv3.weight", "", p + ".bn3", 256, 64, 1, 1, 0, h16);
             b.has_ds = bi == 0;
-            if (b.has_ds) L.conv(b.ds, lab + ".downsample", p + ".downsample.0.weight", "", p + ".downsample.1", 256, 64, 1, 1);
+            if (b.has_ds) L.conv(b.ds, lab + ".downsample", p + ".downsample.0.weight", "", p + ".downsample.1", 256, 64, 1, 1, 0, h16);
             inpl_ = 256;
             hr.layer1.push_back(b);
         }
@@ -460,7 +459,7 @@ int hmv_finalize_weights(hmv_handle h) {
                         Layer l;
                         const std::string q = tp + "." + std::to_string(i);
                         L.conv(l, "transition" + std::to_string(st + 1) + "." + std::to_string(i), q + ".0.weight", "", q + ".1",
-                               hr.ch[i], prec[i], 3, 3, cpad(prec[i]));
+                               hr.ch[i], prec[i], 3, 3, cpad(prec[i]), h16);
                         hr.trans[st][i].push_back(l);
                     }
                 } else {
@@ -470,7 +469,7 @@ int hmv_finalize_weights(hmv_handle h) {
                         Layer l;
                         const std::string q = tp + "." + std::to_string(i) + "." + std::to_string(j);
                         L.conv(l, "transition" + std::to_string(st + 1) + "." + std::to_string(i) + "." + std::to_string(j),
-                               q + ".0.weight", "", q + ".1", outc, cin, 3, 3, cpad(cin));
+                               q + ".0.weight", "", q + ".1", outc, cin, 3, 3, cpad(cin), h16);
                         hr.trans[st][i].push_back(l);
                         cin = outc;
                     }
@@ -486,8 +485,8 @@ int hmv_finalize_weights(hmv_handle h) {
                     for (int blk = 0; blk < 4; ++blk) {
                         const std::string bp = mp + ".branches." + std::to_string(b) + "." + std::to_string(blk);
                         const std::string bl = ml + ".b" + std::to_string(b) + "." + std::to_string(blk);
-                        L.conv(M.br[b][blk][0], bl + ".conv1", bp + ".conv1.weight", "", bp + ".bn1", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]));
-                        L.conv(M.br[b][blk][1], bl + ".conv2", bp + ".conv2.weight", "", bp + ".bn2", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]));
+                        L.conv(M.br[b][blk][0], bl + ".conv1", bp + ".conv1.weight", "", bp + ".bn1", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]), h16);
+                        L.conv(M.br[b][blk][1], bl + ".conv2", bp + ".conv2.weight", "", bp + ".bn2", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]), h16);
                     }
                 for (int i = 0; i < nbr; ++i)
                     for (int j = 0; j < nbr; ++j) {
@@ -495,14 +494,14 @@ int hmv_finalize_weights(hmv_handle h) {
                         const std::string fl = ml + ".fuse" + std::to_string(i) + std::to_string(j);
                         if (j > i) {
                             Layer l;
-                            L.conv(l, fl, fp + ".0.weight", "", fp + ".1", hr.ch[i], hr.ch[j], 1, 1, cpad(hr.ch[j]));
+                            L.conv(l, fl, fp + ".0.weight", "", fp + ".1", hr.ch[i], hr.ch[j], 1, 1, cpad(hr.ch[j]), h16);
                             M.fuse[i][j].push_back(l);
                         } else if (j < i) {
                             for (int q = 0; q < i - j; ++q) {
                                 const int outc = (q == i - j - 1) ? hr.ch[i] : hr.ch[j];
                                 Layer l;
                                 const std::string fq = fp + "." + std::to_string(q);
-                                L.conv(l, fl + "." + std::to_string(q), fq + ".0.weight", "", fq + ".1", outc, hr.ch[j], 3, 3, cpad(hr.ch[j]));
+                                L.conv(l, fl + "." + std::to_string(q), fq + ".0.weight", "", fq + ".1", outc, hr.ch[j], 3, 3, cpad(hr.ch[j]), h16);
                                 M.fuse[i][j].push_back(l);
                             }
                         }
@@ -512,7 +511,7 @@ int hmv_finalize_weights(hmv_handle h) {
             for (int i = 0; i < nbr; ++i) prec[i] = hr.ch[i];
         }
         // pose_net = nn.Conv2d(C0, 21, 3, stride 2, padding 1): handmvnet.py:51-57
-        L.conv(h->pose0, "pose_net", "pose_net.weight", "pose_net.bias", "", NJ, c.channels[0], 3, 3, cpad(c.channels[0]));
+        L.conv(h->pose0, "pose_net", "pose_net.weight", "pose_net.bias", "", NJ, c.channels[0], 3, 3, cpad(c.channels[0]), h16);
     } else {
     // ---- backbone: resnet.py:162-177, 189-203
     L.conv(h->stem, "stem", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 7, 7, /*cin_pad=*/h16 ? 8 : 4, h16);
@@ -790,7 +789,7 @@ struct Runner {
         p.rg_out = rg_out; p.rg_in = rg_in;
         p.scatter = scatter; p.osy = scatter ? 2 : 1; p.osx = scatter ? 2 : 1; p.ooy = ooy; p.oox = oox;
         p.up = up; p.fill = fill ? 1 : 0;
-        const ConvTile tile = conv_pick_tile(p.M, p.Cout, p.K);
+        const ConvTile tile = conv_pick_tile(p.M, p.Cout, p.K, L.f16, res != nullptr);
         ProfRec *pr = nullptr;
         if (h->profiling) {
             if (h->prof_used == h->prof.size()) {
@@ -841,30 +840,31 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         // ================= HighResolutionNet.forward (hrnet.py:357-393) =================
         const HrNet &hr = h->hr;
         float *in4 = R.alloc((size_t)N * H * W * 4);
-        if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, false, in4, s));
+        if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, h16, in4, s));
+        else if (h16) LAUNCH(launch_nchw_to_nhwc8_f16(x, in4, N, H, W, s));
         else LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
         const int H1 = (H + 2 - 3) / 2 + 1, W1 = (W + 2 - 3) / 2 + 1, H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
-        float *c1 = R.alloc((size_t)N * H1 * W1 * 64);
-        R.conv(hr.conv1, in4, N, H, W, 2, 1, 1, c1, 64, nullptr, 0, ACT_RELU, H1, W1);
+        float *c1 = R.alloc(ACT((size_t)N * H1 * W1 * 64));
+        R.conv(hr.conv1, in4, N, H, W, 2, 1, 1, c1, 64, nullptr, 0, ACT_RELU, H1, W1, 0, 0, 0, 0, 0, h16);
         R.release(in4);
-        float *cur = R.alloc((size_t)N * H2 * W2 * 64);
-        R.conv(hr.conv2, c1, N, H1, W1, 2, 1, 1, cur, 64, nullptr, 0, ACT_RELU, H2, W2);
+        float *cur = R.alloc(ACT((size_t)N * H2 * W2 * 64));
+        R.conv(hr.conv2, c1, N, H1, W1, 2, 1, 1, cur, 64, nullptr, 0, ACT_RELU, H2, W2, 0, 0, 0, 0, 0, h16);
         R.release(c1);
         for (const Block &b : hr.layer1) {   // 4 Bottlenecks, planes 64 -> 256 channels
-            float *t1 = R.alloc((size_t)N * H2 * W2 * 64);
-            R.conv(b.c1, cur, N, H2, W2, 1, 0, 0, t1, 64, nullptr, 0, ACT_RELU, H2, W2);
-            float *t2 = R.alloc((size_t)N * H2 * W2 * 64);
-            R.conv(b.c2, t1, N, H2, W2, 1, 1, 1, t2, 64, nullptr, 0, ACT_RELU, H2, W2);
+            float *t1 = R.alloc(ACT((size_t)N * H2 * W2 * 64));
+            R.conv(b.c1, cur, N, H2, W2, 1, 0, 0, t1, 64, nullptr, 0, ACT_RELU, H2, W2, 0, 0, 0, 0, 0, h16);
+            float *t2 = R.alloc(ACT((size_t)N * H2 * W2 * 64));
+            R.conv(b.c2, t1, N, H2, W2, 1, 1, 1, t2, 64, nullptr, 0, ACT_RELU, H2, W2, 0, 0, 0, 0, 0, h16);
             R.release(t1);
             const float *res = cur;
             float *dsb = nullptr;
             if (b.has_ds) {
-                dsb = R.alloc((size_t)N * H2 * W2 * 256);
-                R.conv(b.ds, cur, N, H2, W2, 1, 0, 0, dsb, 256, nullptr, 0, ACT_NONE, H2, W2);
+                dsb = R.alloc(ACT((size_t)N * H2 * W2 * 256));
+                R.conv(b.ds, cur, N, H2, W2, 1, 0, 0, dsb, 256, nullptr, 0, ACT_NONE, H2, W2, 0, 0, 0, 0, 0, h16);
                 res = dsb;
             }
-            float *y = R.alloc((size_t)N * H2 * W2 * 256);
-            R.conv(b.c3, t2, N, H2, W2, 1, 0, 0, y, 256, res, 256, ACT_RELU, H2, W2);
+            float *y = R.alloc(ACT((size_t)N * H2 * W2 * 256));
+            R.conv(b.c3, t2, N, H2, W2, 1, 0, 0, y, 256, res, 256, ACT_RELU, H2, W2, 0, 0, 0, 0, 0, h16);
             R.release(t2);
             R.release(dsb);
             R.release(cur);
@@ -881,9 +881,9 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                 if (i < npre) {
                     hs[i] = preh[i]; ws[i] = prew[i];
                     if (!hr.trans[st][i].empty()) {
-                        xs[i] = R.alloc((size_t)N * hs[i] * ws[i] * cp);
+                        xs[i] = R.alloc(ACT((size_t)N * hs[i] * ws[i] * cp));
                         R.conv(hr.trans[st][i][0], pre[i], N, preh[i], prew[i], 1, 1, 1, xs[i], cp, nullptr, 0, ACT_RELU, hs[i], ws[i],
-                               0, 0, 0, 0, 0, false, 0, /*fill=*/true);
+                               0, 0, 0, 0, 0, h16, 0, /*fill=*/true);
                     } else {
                         xs[i] = pre[i];   // x_list.append(y_list[i]): the same tensor
                         moved[i] = true;
@@ -894,8 +894,8 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                     int hh_ = preh[npre - 1], ww_ = prew[npre - 1];
                     for (const Layer &l : hr.trans[st][i]) {
                         const int ho = (hh_ + 2 - 3) / 2 + 1, wo = (ww_ + 2 - 3) / 2 + 1, cpo = cpad(l.Cout);
-                        float *o = R.alloc((size_t)N * ho * wo * cpo);
-                        R.conv(l, src, N, hh_, ww_, 2, 1, 1, o, cpo, nullptr, 0, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, false, 0, true);
+                        float *o = R.alloc(ACT((size_t)N * ho * wo * cpo));
+                        R.conv(l, src, N, hh_, ww_, 2, 1, 1, o, cpo, nullptr, 0, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, h16, 0, true);
                         R.release(tmp);
                         tmp = o; src = o; hh_ = ho; ww_ = wo;
                     }
@@ -908,11 +908,11 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                 for (int b = 0; b < nbr; ++b) {
                     const int cp = cpad(hr.ch[b]);
                     for (int blk = 0; blk < 4; ++blk) {
-                        float *t = R.alloc((size_t)N * hs[b] * ws[b] * cp);
+                        float *t = R.alloc(ACT((size_t)N * hs[b] * ws[b] * cp));
                         R.conv(M.br[b][blk][0], xs[b], N, hs[b], ws[b], 1, 1, 1, t, cp, nullptr, 0, ACT_RELU, hs[b], ws[b], 0, 0, 0, 0, 0,
-                               false, 0, true);
-                        float *y = R.alloc((size_t)N * hs[b] * ws[b] * cp);
-                        R.conv(M.br[b][blk][1], t, N, hs[b], ws[b], 1, 1, 1, y, cp, xs[b], cp, ACT_RELU, hs[b], ws[b], 0, 0, 0, 0, 0, false,
+                               h16, 0, true);
+                        float *y = R.alloc(ACT((size_t)N * hs[b] * ws[b] * cp));
+                        R.conv(M.br[b][blk][1], t, N, hs[b], ws[b], 1, 1, 1, y, cp, xs[b], cp, ACT_RELU, hs[b], ws[b], 0, 0, 0, 0, 0, h16,
                                0, true);
                         R.release(t);
                         R.release(xs[b]);
@@ -932,10 +932,10 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                         const bool first = nterm == 0, last = nterm == nbr - 2;
                         const float *res = first ? xs[i] : running;
                         const int act = last ? ACT_RELU : ACT_NONE;
-                        float *o = R.alloc((size_t)N * hs[i] * ws[i] * cpi);
+                        float *o = R.alloc(ACT((size_t)N * hs[i] * ws[i] * cpi));
                         if (j > i) {
                             R.conv(M.fuse[i][j][0], xs[j], N, hs[j], ws[j], 1, 0, 0, o, cpi, res, cpi, act, hs[i], ws[i], 0, 0, 0, 0, 0,
-                                   false, /*up=*/j - i, true);
+                                   h16, /*up=*/j - i, true);
                         } else {
                             const float *src = xs[j];
                             float *tmp = nullptr;
@@ -945,11 +945,11 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                                 const Layer &l = M.fuse[i][j][q];
                                 const int ho = (hh_ + 2 - 3) / 2 + 1, wo = (ww_ + 2 - 3) / 2 + 1;
                                 if (q == nq - 1) {
-                                    R.conv(l, src, N, hh_, ww_, 2, 1, 1, o, cpi, res, cpi, act, ho, wo, 0, 0, 0, 0, 0, false, 0, true);
+                                    R.conv(l, src, N, hh_, ww_, 2, 1, 1, o, cpi, res, cpi, act, ho, wo, 0, 0, 0, 0, 0, h16, 0, true);
                                 } else {
                                     const int cpo = cpad(l.Cout);
-                                    float *t = R.alloc((size_t)N * ho * wo * cpo);
-                                    R.conv(l, src, N, hh_, ww_, 2, 1, 1, t, cpo, nullptr, 0, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, false, 0, true);
+                                    float *t = R.alloc(ACT((size_t)N * ho * wo * cpo));
+                                    R.conv(l, src, N, hh_, ww_, 2, 1, 1, t, cpo, nullptr, 0, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, h16, 0, true);
                                     R.release(tmp);
                                     tmp = t; src = t;
                                 }
@@ -971,7 +971,10 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         (void)prec;
         nkeep = 4;
         for (int i = 0; i < 4; ++i) { lvl[i] = pre[i]; lvc[i] = hr.ch[i]; lvld[i] = cpad(hr.ch[i]); lvh[i] = preh[i]; lvw[i] = prew[i]; }
-        if (h->capture && !dry && h->cap_feat0) LAUNCH(launch_nhwc_to_nchw(lvl[0], h->cap_feat0, N, lvh[0], lvw[0], lvc[0], s, lvld[0]));
+        if (h->capture && !dry && h->cap_feat0) {
+            if (h16) LAUNCH(launch_nhwc_f16_to_nchw(lvl[0], h->cap_feat0, N, lvh[0], lvw[0], lvc[0], s));
+            else LAUNCH(launch_nhwc_to_nchw(lvl[0], h->cap_feat0, N, lvh[0], lvw[0], lvc[0], s, lvld[0]));
+        }
         // pose_net = Conv2d(C0, 21, 3, stride 2, padding 1) on the highest-resolution branch (handmvnet.py:51-57, 180)
         hmh = (lvh[0] + 2 - 3) / 2 + 1; hmw = (lvw[0] + 2 - 3) / 2 + 1;
         hm = R.alloc((size_t)N * hmh * hmw * 32);

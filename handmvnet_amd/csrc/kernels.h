@@ -46,7 +46,7 @@ enum ConvTile { TILE_128x32 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x128
 int conv_tile_bn(ConvTile t);                       // N-tile width of a tile config
 const char *conv_tile_name(ConvTile t, int mode);   // mode: 0 taps, 1 1x1/GEMM, 2 dense K (stem, Cin % 32 != 0)
 const char *conv_tile_name_f16(ConvTile t, int mode);
-ConvTile conv_pick_tile(int M, int Cout, int K);
+ConvTile conv_pick_tile(int M, int Cout, int K, bool f16 = false, bool has_res = false);
 ConvTile conv_dense_tile(ConvTile t, bool f16);     // the tile a dense-K (Cin % 32 != 0) launch really uses
 bool conv_partial_n(ConvTile t, int Cout);          // launch_conv uses the block-skipping instantiation
 // fills mtiles/ntiles and launches

@@ -204,7 +204,7 @@ def test_state_dict_errors_match_reference_behaviour():
 #   * joints_cam: <= 0.15 rel-L2, dominated by exactly those flips (measured 5e-4 .. 7.6e-2).
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["tiny_r50", "tiny_r18", "cfg1_r50_v4_128", "cfg2s_r18_v4_256", "cfg3s_r50_v8_256",
-                                  "r50_wocam_nn", "r34_onelevel", "r18_single_view"])
+                                  "r50_wocam_nn", "r34_onelevel", "r18_single_view", "hr40_tiny", "hr40_v4_128", "hr64_tiny"])
 def test_fp16_path_within_its_stated_tolerance(name):
     m, cfg, sd, (x, bbox, intr), fx = _model(name)
     m.half()

@@ -573,7 +573,7 @@ hipError_t launch_copy_rows(const float *in, int ldi, float *out, int ldo, int r
 // lane owns one output pixel, walks the separable triangle filter of torch's antialiased bilinear resize
 // (aten `_compute_indices_min_size_weights_aa`: support = max(scale, 1), weights 1 - |x| / max(scale, 1),
 // renormalised over the taps that fall inside the window) and reads window pixels that leave the frame as 0.
-// An empty box (x2 <= x1 or y2 <= y1) is the reference's "no visible joint" black view.
+// An empty box (x2 <= x1 or y2 <= y1; also a window wider than 65536 px) is the reference's "no visible joint" black view.
 struct FrameNorm { float mean[3], inv_std[3]; };
 
 __device__ __forceinline__ void aa_span(int o, int in_size, float scale, float &center, float &invscale, int &first, int &count) {
@@ -596,29 +596,33 @@ __global__ void frames_to_input_kernel(const uint8_t *__restrict__ frames, const
         const size_t n = t / S_h;
         const int x1 = boxes[n * 4], y1 = boxes[n * 4 + 1], x2 = boxes[n * 4 + 2], y2 = boxes[n * 4 + 3];
         float acc[3] = {0.f, 0.f, 0.f};
-        if (x2 > x1 && y2 > y1) {
-            const int cw = x2 - x1, ch = y2 - y1;
+        // windows wider than kMaxWindow px are treated like empty ones: a garbage box must not turn into an unbounded loop
+        constexpr int kMaxWindow = 1 << 16;
+        const long long cwl = (long long)x2 - x1, chl = (long long)y2 - y1;
+        if (cwl > 0 && chl > 0 && cwl <= kMaxWindow && chl <= kMaxWindow) {
+            const int cw = (int)cwl, ch = (int)chl;
             float cx, ix, cy, iy;
             int fx, nx, fy, ny;
             aa_span(ox, cw, (float)cw / (float)S_w, cx, ix, fx, nx);
             aa_span(oy, ch, (float)ch / (float)S_h, cy, iy, fy, ny);
             const uint8_t *img = frames + n * (size_t)Hf * Wf * 3;
+            // weight sums run over ALL taps of the window; pixel reads only over the taps that fall inside the frame
             float wysum = 0.f, wxsum = 0.f;
             for (int a = 0; a < nx; ++a) wxsum += fmaxf(0.f, 1.f - fabsf((float)(a + fx) - cx + 0.5f) * ix);
-            for (int b = 0; b < ny; ++b) {
+            for (int b = 0; b < ny; ++b) wysum += fmaxf(0.f, 1.f - fabsf((float)(b + fy) - cy + 0.5f) * iy);
+            const long long ox0 = (long long)fx + x1, oy0 = (long long)fy + y1;   // frame coordinates of tap 0
+            const int a_lo = (int)(ox0 < 0 ? (-ox0 < nx ? -ox0 : nx) : 0), a_hi = (int)(ox0 + nx > Wf ? (Wf - ox0 > 0 ? Wf - ox0 : 0) : nx);
+            const int b_lo = (int)(oy0 < 0 ? (-oy0 < ny ? -oy0 : ny) : 0), b_hi = (int)(oy0 + ny > Hf ? (Hf - oy0 > 0 ? Hf - oy0 : 0) : ny);
+            for (int b = b_lo; b < b_hi; ++b) {
                 const float wy = fmaxf(0.f, 1.f - fabsf((float)(b + fy) - cy + 0.5f) * iy);
-                wysum += wy;
-                const int sy = fy + b + y1;
-                if ((unsigned)sy >= (unsigned)Hf || wy == 0.f) continue;
+                if (wy == 0.f) continue;
+                const uint8_t *line = img + ((size_t)(oy0 + b) * Wf + (size_t)(ox0 + a_lo)) * 3;
                 float row[3] = {0.f, 0.f, 0.f};
-                for (int a = 0; a < nx; ++a) {
-                    const int sx = fx + a + x1;
-                    if ((unsigned)sx >= (unsigned)Wf) continue;
+                for (int a = a_lo; a < a_hi; ++a, line += 3) {
                     const float wx = fmaxf(0.f, 1.f - fabsf((float)(a + fx) - cx + 0.5f) * ix);
-                    const uint8_t *px = img + ((size_t)sy * Wf + sx) * 3;
-                    row[0] += wx * (float)px[0];
-                    row[1] += wx * (float)px[1];
-                    row[2] += wx * (float)px[2];
+                    row[0] += wx * (float)line[0];
+                    row[1] += wx * (float)line[1];
+                    row[2] += wx * (float)line[2];
                 }
                 acc[0] += wy * row[0];
                 acc[1] += wy * row[1];

@@ -141,7 +141,7 @@ int hmv_graph_stats(hmv_handle h, int32_t *cached, int64_t *replays);
  * -> Normalize(mean, std)); here that is one kernel in front of the stem conv and the fp32 NCHW batch never exists.
  * frames: device uint8 [batch*V][frame_h][frame_w][3] (HWC, the channel order the weights were trained on);
  * crop_boxes: device int32 [batch*V][4] = x1,y1,x2,y2 of the (square or not) crop window in frame pixels -- may leave the
- * frame (zeros are read there); an EMPTY window (x2<=x1 or y2<=y1) yields the reference's black "no visible joint" view;
+ * frame (zeros are read there); an EMPTY window (x2<=x1 or y2<=y1, or wider than 65536 px) yields the reference's black "no visible joint" view;
  * mean/std: host float[3] (ho3d.py:38-39 uses the ImageNet constants).  The window is resized to cfg.height x cfg.width.
  * bbox / intrinsic / outputs / stream exactly as hmv_forward (bbox is normally crop_boxes as fp32, ho3d.py:198). */
 int hmv_forward_frames(hmv_handle h, int32_t batch, const uint8_t *frames, int32_t frame_h, int32_t frame_w, const int32_t *crop_boxes,

@@ -97,6 +97,19 @@ def test_prepare_frames_full_size_properties():
     assert bool(((a >= lo - 1e-5) & (a <= hi + 1e-5)).all())
 
 
+def test_garbage_boxes_are_bounded_and_black():
+    """int32 extremes and absurd windows: no overflow, no unbounded loop; they come out as the black view."""
+    from handmvnet_amd.frames import prepare_frames
+    frames = torch.full((4, 48, 64, 3), 200, dtype=torch.uint8, device="cuda:0")
+    boxes = torch.tensor([[-2 ** 31, -2 ** 31, 2 ** 31 - 1, 2 ** 31 - 1], [0, 0, 2 ** 30, 2 ** 30], [10, 10, 5, 40],
+                          [-1000, -1000, 1000, 1000]], dtype=torch.int32, device="cuda:0")
+    out = prepare_frames(frames, boxes, 32).cpu().numpy()
+    black = ((0 - fo.MEAN) / fo.STD)[:, None, None]
+    assert np.allclose(out[:3], black)
+    want = fo.prepare_view(np.full((48, 64, 3), 200, np.uint8), [-1000, -1000, 1000, 1000], 32)   # a legal window 30x the frame
+    assert np.abs(out[3] - want).max() < 5e-6
+
+
 def test_forward_frames_argument_errors():
     from handmvnet_amd import HandMvNet, _lib
     cfg, (tp, mp, dp), sd, (x, bbox, intr), fx = load_case("tiny_r18")

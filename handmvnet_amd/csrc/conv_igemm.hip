@@ -73,15 +73,16 @@ enum { MODE_TAPS = 0,   // general R x S convolution, Cin % 32 == 0: the tap of 
 // SR = WGM*AS*32 rows of BN+4 floats.  AS is the largest divisor of TM that fits the LDS budget
 // without growing the allocation (much) beyond the two tile buffers.
 // (KB is given in 4-byte units here: the kernels pass KB * sizeof(T) / 4)
-constexpr int stage_blocks(int BM, int BN, int WGM, int KB) {
+constexpr int stage_blocks(int BM, int BN, int WGM, int KB, bool full = false) {
     const int TM = BM / WGM / 32;
+    if (full) return TM;   // the row-decomposed epilogue sums neighbouring rows: the whole tile is staged at once
     int as = TM;
     while (as > 1 && (TM % as != 0 || WGM * as * 32 * (BN + 4) > 2 * (BM + BN) * KB + 1024)) --as;
     return as;
 }
-constexpr int lds_floats(int BM, int BN, int WGM, int KB) {
+constexpr int lds_floats(int BM, int BN, int WGM, int KB, bool full = false) {
     const int tile = 2 * (BM + BN) * KB;
-    const int stage = WGM * stage_blocks(BM, BN, WGM, KB) * 32 * (BN + 4);
+    const int stage = WGM * stage_blocks(BM, BN, WGM, KB, full) * 32 * (BN + 4);
     return tile > stage ? tile : stage;
 }
 
@@ -100,7 +101,12 @@ constexpr int lds_floats(int BM, int BN, int WGM, int KB) {
 // PARTN = true (chosen when the last N-tile holds at least one all-padding 32-column block, e.g. Cout = 80 / 160 / 320
 // under 128- or 256-wide tiles): a wave skips the fragment reads and MFMAs of its all-padding blocks, and the waves are
 // mapped to sub-tiles so that the two waves sharing a SIMD cover complementary column ranges.
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false>
+// RD = true: row-decomposed 3x3 convolution for narrow outputs (HRNet's 40-channel branch).  The GEMM runs a 3x1
+// convolution (taps r only) against weights whose N index is (s, cout): N' = 3*Cout = 120 fills a 128-wide tile where
+// Cout = 40 fills 40 of 64 columns, and K' = 3*Cin = 120 pads to 128 instead of 360 to 384 -- 1.5x fewer MFMAs.  The
+// epilogue then sums the three column groups of horizontally neighbouring pixels, out[m][n] = sum_s G[m + s - 1][s*Cout + n],
+// which needs no halo because a tile always covers whole image rows (BM % Wo == 0, checked by launch_conv).
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p) {
     constexpr bool F16 = sizeof(T) == 2;
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
@@ -114,10 +120,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int AP = BM / RPS, BP = BN / RPS;
     constexpr int LDC = BN + 4;
-    constexpr int AS = stage_blocks(BM, BN, WGM, KB4), SR = WGM * AS * 32;
+    constexpr int AS = stage_blocks(BM, BN, WGM, KB4, RD), SR = WGM * AS * 32;
     static_assert(KB == CH || KB == CH / 2, "k-step");
     static_assert(BM % RPS == 0 && BN % RPS == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
-    static_assert(TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM, KB4), "epilogue staging");
+    static_assert(TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM, KB4, RD), "epilogue staging");
+    static_assert(!RD || (!GENERIC && !PARTN), "row-decomposed epilogue");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     T *sA = reinterpret_cast<T *>(smem);   // [2][BM][KB]
     T *sB = sA + 2 * BM * KB;              // [2][BN][KB]
@@ -333,7 +340,37 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             return ((size_t)n * (p.Ho * p.osy) + (ho * p.osy + p.ooy)) * (size_t)(p.Wo * p.osx) + (wo * p.osx + p.oox);
         };
-        if (vec) {
+        if constexpr (RD) {
+            // AS == TM: staged row == tile row.  One thread per 4 output channels of one pixel.
+            const int cv = p.rd_cout >> 2;
+            const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+            for (int idx = tid; idx < BM * cv; idx += NT) {
+                const int r = idx / cv, c4 = idx - r * cv;
+                const int m = mt * BM + r;
+                if (m >= p.M) continue;
+                const int wo = m % p.Wo;
+                f32x4 t = *reinterpret_cast<const f32x4 *>(p.bias + 4 * c4);
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx)
+                    if ((unsigned)(wo + sx - 1) < (unsigned)p.Wo)
+                        t += *reinterpret_cast<const f32x4 *>(&sC[(r + sx - 1) * LDC + sx * p.rd_cout + 4 * c4]);
+                if (p.res) {
+                    if (p.res_f16) {
+                        const f16x4 hv = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(p.res) + (size_t)m * p.ldr + 4 * c4);
+                        t += f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                    } else {
+                        t += *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.res) + (size_t)m * p.ldr + 4 * c4);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], lo);
+                if (p.out_f16)
+                    *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc + 4 * c4) =
+                        f16x4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+                else
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out) + (size_t)m * p.ldc + 4 * c4) = t;
+            }
+        } else if (vec) {
             constexpr int TPR = BN / 4, RPP = NT / TPR, NPASS = SR / RPP, UB = NPASS < HMV_UB ? NPASS : HMV_UB;
             static_assert(SR % RPP == 0 && NPASS % UB == 0, "staging pass shape");
             const int c4 = tid % TPR, r0 = tid / TPR;
@@ -437,14 +474,14 @@ int conv_tile_bn(ConvTile t) {
 // Family name = one rocprofv3 symbol: conv_igemm<T, BM, BN, WGM, WGN, MODE, false, KB>
 static const char *kTileShape[TILE_COUNT] = {"128x32", "128x64", "128x128", "256x128", "128x256", "256x256", "128x128,k16",
                                               "128x256,k16", "256x128,k16", "64x64"};
-static const char *tile_name(const char *dtype, ConvTile t, int mode, bool partn = false) {
-    static char names[2][TILE_COUNT][3][2][56];
+static const char *tile_name(const char *dtype, ConvTile t, int mode, bool partn = false, bool rd = false) {
+    static char names[2][TILE_COUNT][3][3][56];
     if (t < 0 || t >= TILE_COUNT || mode < 0 || mode > 2) return "conv_igemm<?>";
     const int d = dtype[1] == '1';   // "f16" / "f32"
-    char *n = names[d][t][mode][partn ? 1 : 0];
+    char *n = names[d][t][mode][rd ? 2 : (partn ? 1 : 0)];
     if (!n[0])
         snprintf(n, sizeof(names[0][0][0][0]), "conv_igemm_%s<%s,%s%s>", dtype, kTileShape[t],
-                 mode == 0 ? "taps" : (mode == 1 ? "1x1" : "dense"), partn ? ",skipN" : "");
+                 mode == 0 ? "taps" : (mode == 1 ? "1x1" : "dense"), rd ? ",rowsum" : (partn ? ",skipN" : ""));
     return n;
 }
 // fp16 has no half-step variants of the big tiles: they run as their full-step tile
@@ -499,11 +536,11 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
     return TILE_128x32;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false>
 static hipError_t launch_one(ConvParams p, hipStream_t s) {
     static bool configured = false;
-    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4) * sizeof(float);
-    auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN>;
+    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4, RD) * sizeof(float);
+    auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -544,6 +581,23 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         tile = TILE_128x128;   // the rarely used epilogue paths exist only for the 4-wave tiles
     const int ch = p.in_f16 ? 64 : 32, epc = p.in_f16 ? 8 : 4;
     const bool dense = p.Cin % ch != 0;
+    if (p.rd_cout) {   // row-decomposed 3x3 (see conv_igemm): the caller passes the 3x1 GEMM (R = 3, S = 1, Cout = 3 * rd_cout)
+        if (generic || p.R != 3 || p.S != 1 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 0 || p.Cout != 3 * p.rd_cout || p.Cout > 128 ||
+            (p.rd_cout & 3) || (p.ldc & 3) || (p.res && (p.ldr & 3)) || 128 % p.Wo != 0 || p.Ho != p.H || p.Wo != p.W)
+            return hipErrorInvalidValue;
+        if (dense) {
+            if (p.Cin % epc != 0 || p.lda % epc != 0 || p.Kpad > (1 << 16)) return hipErrorInvalidValue;
+            p.cpt = p.Cin / epc;
+            p.cpt_magic = p.cpt > 1 ? (unsigned)(0xFFFFFFFFu / (unsigned)p.cpt) + 1u : 0u;
+            p.s_magic = 0u;
+        }
+        if (name) *name = tile_name(p.in_f16 ? "f16" : "f32", TILE_128x128, dense ? 2 : 0, false, true);
+        if (p.in_f16)
+            return dense ? launch_one<_Float16, 128, 128, 2, 2, MODE_DENSE, false, 64, false, true>(p, s)
+                         : launch_one<_Float16, 128, 128, 2, 2, MODE_TAPS, false, 64, false, true>(p, s);
+        return dense ? launch_one<float, 128, 128, 2, 2, MODE_DENSE, false, 32, false, true>(p, s)
+                     : launch_one<float, 128, 128, 2, 2, MODE_TAPS, false, 32, false, true>(p, s);
+    }
     if (dense) {
         if (p.Cin % epc != 0 || p.lda % epc != 0 || generic || p.Kpad > (1 << 16)) return hipErrorInvalidValue;
         p.cpt = p.Cin / epc;

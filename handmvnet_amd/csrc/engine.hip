@@ -44,6 +44,7 @@ struct Layer {
     float *w = nullptr, *bias = nullptr;
     int Cin = 0, Cout = 0, R = 1, S = 1, K = 0, Kpad = 0, Cout_pad = 0;
     int Kreal = 0;      // reduction length without channel padding (FLOP accounting)
+    int rd_cout = 0;    // row-decomposed 3x3 (conv_igemm.hip, RD): the real Cout; Cout / R / S then describe the 3x1 GEMM
     bool f16 = false;   // operands (activations + packed weights) are fp16; bias stays fp32
     std::string label;
 };
@@ -312,7 +313,7 @@ struct Loader {
 
     // nn.Conv2d weight OIHW (+ optional bias key) followed by an optional BN
     void conv(Layer &L, const std::string &label, const std::string &wkey, const std::string &bkey, const std::string &bn,
-              int Cout, int Cin, int R, int S, int cin_pad = 0, bool f16 = false) {
+              int Cout, int Cin, int R, int S, int cin_pad = 0, bool f16 = false, bool rd = false) {
         const HostTensor *w = get(wkey, {Cout, Cin, R, S});
         const HostTensor *cb = bkey.empty() ? nullptr : get(bkey, {Cout});
         std::vector<double> sc, sh;
@@ -335,6 +336,33 @@ struct Loader {
             if (c >= Cin) return 0.f;
             return wd[(((size_t)o * Cin + c) * R + tap / S) * S + tap % S];
         };
+        if (rd && R == 3 && S == 3 && !cb) {
+            // row-decomposed packing: GEMM output o' = (s, n), reduction k = (r, c); bias / BN shift live in group s = 0
+            const int CH = f16 ? 64 : 32;
+            auto wt3 = [=](int o2, int k) -> float {
+                const int sx = o2 / Cout, n = o2 % Cout;
+                int c, r;
+                if (cp % CH == 0) {
+                    const int chunk = k / (CH * 3), rem = k % (CH * 3);
+                    r = rem / CH;
+                    c = chunk * CH + rem % CH;
+                } else {
+                    c = k % cp;
+                    r = k / cp;
+                }
+                if (c >= Cin) return 0.f;
+                return wd[(((size_t)n * Cin + c) * 3 + r) * 3 + sx];
+            };
+            std::vector<double> sc3(3 * Cout, 1.0), sh3(3 * Cout, 0.0);
+            for (int o2 = 0; o2 < 3 * Cout; ++o2) {
+                if (has_bn) sc3[o2] = sc[o2 % Cout];
+                if (has_bn && o2 < Cout) sh3[o2] = sh[o2];
+            }
+            finish(L, label, cp, 3 * Cout, 3, 1, 3 * cp, wt3, &sc3, &sh3, nullptr, f16);
+            L.rd_cout = Cout;
+            L.Kreal = 3 * Cin;   // (3 * Cout) x (3 * Cin) = Cout x 9 * Cin: the FLOP accounting sees the real convolution
+            return;
+        }
         finish(L, label, cp, Cout, R, S, R * S * cp, wt, has_bn ? &sc : nullptr, has_bn ? &sh : nullptr,
                cb ? cb->data.data() : nullptr, f16);
         L.Kreal = R * S * Cin;
@@ -433,6 +461,9 @@ int hmv_finalize_weights(hmv_handle h) {
         HrNet &hr = h->hr;
         hr = HrNet();
         for (int i = 0; i < 4; ++i) hr.ch[i] = kHrChannels[c.backbone - HMV_HRNET_W40][i];
+        // the highest-resolution branch (H/4 x W/4) of w40 has 40 channels: its stride-1 3x3 convs run row-decomposed
+        // when a 128-row tile covers whole image rows (conv_igemm.hip, RD)
+        const bool rd0 = 3 * hr.ch[0] <= 128 && hr.ch[0] % 4 == 0 && 128 % (c.width / 4) == 0 && !getenv("HMV_NO_ROWSUM");
         L.conv(hr.conv1, "stem.conv1", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 3, 3, /*cin_pad=*/h16 ? 8 : 4, h16);
         L.conv(hr.conv2, "stem.conv2", "backbone.conv2.weight", "", "backbone.bn2", 64, 64, 3, 3, 0, h16);
         int inpl_ = 64;
@@ -459,7 +490,7 @@ int hmv_finalize_weights(hmv_handle h) {
                         Layer l;
                         const std::string q = tp + "." + std::to_string(i);
                         L.conv(l, "transition" + std::to_string(st + 1) + "." + std::to_string(i), q + ".0.weight", "", q + ".1",
-                               hr.ch[i], prec[i], 3, 3, cpad(prec[i]), h16);
+                               hr.ch[i], prec[i], 3, 3, cpad(prec[i]), h16, i == 0 && rd0);
                         hr.trans[st][i].push_back(l);
                     }
                 } else {
@@ -485,8 +516,8 @@ int hmv_finalize_weights(hmv_handle h) {
                     for (int blk = 0; blk < 4; ++blk) {
                         const std::string bp = mp + ".branches." + std::to_string(b) + "." + std::to_string(blk);
                         const std::string bl = ml + ".b" + std::to_string(b) + "." + std::to_string(blk);
-                        L.conv(M.br[b][blk][0], bl + ".conv1", bp + ".conv1.weight", "", bp + ".bn1", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]), h16);
-                        L.conv(M.br[b][blk][1], bl + ".conv2", bp + ".conv2.weight", "", bp + ".bn2", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]), h16);
+                        L.conv(M.br[b][blk][0], bl + ".conv1", bp + ".conv1.weight", "", bp + ".bn1", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]), h16, b == 0 && rd0);
+                        L.conv(M.br[b][blk][1], bl + ".conv2", bp + ".conv2.weight", "", bp + ".bn2", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]), h16, b == 0 && rd0);
                     }
                 for (int i = 0; i < nbr; ++i)
                     for (int j = 0; j < nbr; ++j) {
@@ -789,6 +820,7 @@ struct Runner {
         p.rg_out = rg_out; p.rg_in = rg_in;
         p.scatter = scatter; p.osy = scatter ? 2 : 1; p.osx = scatter ? 2 : 1; p.ooy = ooy; p.oox = oox;
         p.up = up; p.fill = fill ? 1 : 0;
+        if (L.rd_cout) { p.rd_cout = L.rd_cout; p.pad_w = 0; }   // L.R x L.S is the 3x1 GEMM, the epilogue sums the s groups
         const ConvTile tile = conv_pick_tile(p.M, p.Cout, p.K, L.f16, res != nullptr);
         ProfRec *pr = nullptr;
         if (h->profiling) {

@@ -36,6 +36,7 @@ struct ConvParams {
     const float *zero;  // 256 bytes of zeros (filled in by launch_conv)
     int cpt;            // dense mode: 16-byte vectors per tap (Cin / 4, or Cin / 8 in fp16); filled in by launch_conv
     unsigned cpt_magic, s_magic;   // ceil(2^32 / cpt), ceil(2^32 / S): exact division by multiply-high for k indices < 2^16
+    int rd_cout;        // row-decomposed 3x3 (narrow Cout): the real channel count; Cout is then 3 * rd_cout, R = 3, S = 1
     int lda;            // input pixel stride in floats (0 = Cin)
     int ldw;            // weight row stride in floats (0 = Kpad)
     unsigned long long *dbg;  // diagnostic builds only: per-block {shader cycles, 100 MHz ticks} of the main loop

@@ -181,7 +181,7 @@ struct hmv_engine {
 
     // hipGraph replay of repeated forwards (same batch and the same caller buffers): the ~100 launches of a forward
     // become one graph launch.  Opt-in: measured on MI355X it does not change throughput (eager enqueue already runs
-    // ahead of the GPU, DESIGN.md section 6); what it saves is host time per forward.
+    // ahead of the GPU, DESIGN.md section 5); what it saves is host time per forward.
     // A key is first run eagerly, captured on its second use, replayed from then on.
     typedef std::array<uintptr_t, 12> GraphKey;
     struct GraphEntry { GraphKey key; hipGraphExec_t exec; unsigned long long stamp; };

@@ -128,7 +128,7 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
                    int32_t stride, int32_t pad, int32_t with_residual, int32_t tile, int32_t iters, float *avg_ms);
 
 /* hipGraph replay (opt-in: hmv_set_graphs(h, 1) or HMV_GRAPHS=1 in the environment; it saves host time per forward,
- * not GPU time -- measured throughput on MI355X is the same as eager launches, DESIGN.md section 6).
+ * not GPU time -- measured throughput on MI355X is the same as eager launches, DESIGN.md section 5).
  * A forward whose batch and caller buffers (x / frames, bbox, intrinsic and the three outputs) equal those of an
  * earlier call is captured into a hipGraph on its second occurrence and replayed as ONE launch afterwards
  * (up to 8 buffer sets per handle, least recently used evicted).  Results are bit-identical to the eager path;

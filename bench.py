@@ -103,7 +103,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"], help="f16 = BASELINE configs[4] (fp16 conv stack)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f32x3"],
+                    help="f16 = BASELINE configs[4] (fp16 conv stack); f32x3 = fp32-equivalent (hi, lo) fp16 pairs, three fp16 MFMAs per "
+                         "product (HMV_F32X3, ResNet50-paper)")
     ap.add_argument("--input", default="nchw", choices=["nchw", "frames"],
                     help="nchw = prepared fp32 batch (eval_fps.py protocol, the headline); frames = raw uint8 480x640 camera "
                          "frames + crop windows through hmv_forward_frames (SURVEY 8(f) row 4)")
@@ -146,6 +148,8 @@ def main():
     model.freeze()
     if args.dtype == "f16":
         model.half()
+    elif args.dtype == "f32x3":
+        model.float32x3()
 
     # synthetic frames of this rank's shard, resident in HBM before the timed region
     x, bbox, intr = synth_inputs(cfg, B, 1000 + rank, size)

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
             const unsigned g_ = (unsigned)(ck / EPC + kqs);                                                 \
             const unsigned tap_ = p.cpt == 1 ? g_ : __umulhi(g_, p.cpt_magic);   /* g / (Cin / EPC) */      \
             sc_ = (int)(g_ - tap_ * (unsigned)p.cpt) * EPC;                                                 \
+            if (F16 && p.cwrap && sc_ >= p.cwrap) sc_ -= p.cwrap;   /* split operands: third plane = hi again */ \
             sr_ = p.S == 1 ? (int)tap_ : (int)__umulhi(tap_, p.s_magic);         /* tap / S */              \
             ss_ = (int)tap_ - sr_ * p.S;                                                                    \
             if (tap_ >= (unsigned)(p.R * p.S)) sr_ = 1 << 29;                                               \
@@ -236,6 +237,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
             wptr[i] += KB;                                                                                  \
         }                                                                                                   \
         ck += KB;                                                                                           \
+        if (F16 && MODE == MODE_1X1 && ck == p.cwrap) { /* split operands: after hi, lo walk the hi plane again */ \
+            _Pragma("unroll") for (int i = 0; i < AP; ++i) if (astep[i]) aptr[i] -= p.cwrap;                \
+        }                                                                                                   \
         if (MODE == MODE_TAPS) { /* K order: 32-channel chunk slowest, taps fastest (see ConvParams) */     \
             if (KB == CH / 2 && (ck & (CH / 2))) { /* second half of the same tap */                        \
                 cdelta += CH / 2;                                                                           \
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
                 if (++cs == p.S) {                                                                          \
                     cs = 0;                                                                                 \
                     cdelta += (p.W - p.S) * p.lda;                                                          \
-                    if (++cr == p.R) { cr = 0; cc += CH; cdelta = cc; }                                     \
+                    if (++cr == p.R) { cr = 0; cc += CH; if (F16 && cc == p.cwrap) cc = 0; cdelta = cc; }   \
                 }                                                                                           \
             }                                                                                               \
         }                                                                                                   \
@@ -402,6 +406,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
                                                                       : reinterpret_cast<const _Float16 *>(p.zero);
                             const f16x4 hv = *reinterpret_cast<const f16x4 *>(rp);
                             rv[u] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                            if (p.res_split) {   // [hi | lo] pair: the lo plane sits ldr / 2 further (the zero page is all zeros)
+                                const f16x4 lv = *reinterpret_cast<const f16x4 *>((has_res && okr[u]) ? rp + (p.ldr >> 1) : rp);
+                                rv[u] += f32x4{(float)lv[0], (float)lv[1], (float)lv[2], (float)lv[3]};
+                            }
                         } else {
                             const float *rp = (has_res && okr[u]) ? reinterpret_cast<const float *>(p.res) + rrow * p.ldr + col : p.zero;
                             rv[u] = *reinterpret_cast<const f32x4 *>(rp);
@@ -411,6 +419,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
 #pragma unroll
                     for (int u = 0; u < UB; ++u) {
                         f32x4 t = v[u] + bv + rv[u];
+                        if constexpr (F16) t = v[u] * p.acc_scale + bv + rv[u];   // 1.0 unless the layer's weights were pre-scaled
                         if (GENERIC) {
                             if (p.act == ACT_GELU) {
 #pragma unroll
@@ -423,7 +432,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], lo);
                         if (okr[u]) {
-                            if (p.out_f16)
+                            if (p.out_split) {   // fp32 value -> (hi, lo) fp16 pair, hi + lo == value to ~2^-22
+                                f16x4 hv, lv;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const float c = fminf(fmaxf(t[j], -65504.f), 65504.f);
+                                    hv[j] = (_Float16)c;
+                                    lv[j] = (_Float16)(c - (float)hv[j]);
+                                }
+                                _Float16 *op = reinterpret_cast<_Float16 *>(p.out) + orow[u] * p.ldc + col;
+                                *reinterpret_cast<f16x4 *>(op) = hv;
+                                *reinterpret_cast<f16x4 *>(op + (p.ldc >> 1)) = lv;
+                            } else if (p.out_f16)
                                 *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + orow[u] * p.ldc + col) =
                                     f16x4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
                             else
@@ -573,6 +593,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     p.zero = g_zero_page;
     if (!p.lda) p.lda = p.Cin;
     if (!p.ldw) p.ldw = p.Kpad;
+    p.acc_scale = ldexpf(1.f, -p.acc_shift);
     const bool generic = p.scatter || p.rg_out || p.act == ACT_GELU || p.act == ACT_LEAKY || (p.ldc & 3) ||
                          (p.res && (p.ldr & 3));
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
@@ -581,6 +602,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         tile = TILE_128x128;   // the rarely used epilogue paths exist only for the 4-wave tiles
     const int ch = p.in_f16 ? 64 : 32, epc = p.in_f16 ? 8 : 4;
     const bool dense = p.Cin % ch != 0;
+    if ((p.cwrap || p.res_split || p.out_split || p.acc_shift) && (!p.in_f16 || generic || p.rd_cout)) return hipErrorInvalidValue;
     if (p.rd_cout) {   // row-decomposed 3x3 (see conv_igemm): the caller passes the 3x1 GEMM (R = 3, S = 1, Cout = 3 * rd_cout)
         if (generic || p.R != 3 || p.S != 1 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 0 || p.Cout != 3 * p.rd_cout || p.Cout > 128 ||
             (p.rd_cout & 3) || (p.ldc & 3) || (p.res && (p.ldr & 3)) || 128 % p.Wo != 0 || p.Ho != p.H || p.Wo != p.W)

@@ -44,6 +44,8 @@ struct Layer {
     float *w = nullptr, *bias = nullptr;
     int Cin = 0, Cout = 0, R = 1, S = 1, K = 0, Kpad = 0, Cout_pad = 0;
     int Kreal = 0;      // reduction length without channel padding (FLOP accounting)
+    int acc_shift = 0;  // HMV_F32X3: the packed weights are W * 2^acc_shift, the epilogue scales the accumulator back
+    int plane = 0;      // HMV_F32X3 (split operands): physical channels per (hi | lo) plane; Cin is then the virtual 3 * plane
     int rd_cout = 0;    // row-decomposed 3x3 (conv_igemm.hip, RD): the real Cout; Cout / R / S then describe the 3x1 GEMM
     bool f16 = false;   // operands (activations + packed weights) are fp16; bias stays fp32
     std::string label;
@@ -283,10 +285,13 @@ struct Loader {
         return true;
     }
 
+    bool split = false;   // HMV_F32X3: fp16 layers carry [W_hi | W_hi | W_lo] against the activation sequence hi, lo, hi
+
     // Generic finish: `wt(o, k)` supplies the un-scaled weight for output o, packed index k.
     template <typename F>
     void finish(Layer &L, const std::string &label, int Cin, int Cout, int R, int S, int K, F wt,
-                const std::vector<double> *scale, const std::vector<double> *shift, const float *conv_bias, bool f16 = false) {
+                const std::vector<double> *scale, const std::vector<double> *shift, const float *conv_bias, bool f16 = false,
+                const std::vector<unsigned char> *lo_plane = nullptr) {
         L.label = label;
         L.Cin = Cin; L.Cout = Cout; L.R = R; L.S = S; L.K = K;
         L.f16 = f16;
@@ -303,7 +308,20 @@ struct Loader {
         }
         if (f16) {   // BN scale is folded in fp32/double first, THEN rounded once to fp16
             std::vector<_Float16> wh(w.size());
-            for (size_t i = 0; i < w.size(); ++i) wh[i] = (_Float16)w[i];
+            if (lo_plane) {   // split layers: scale by a power of two so that max |W| ~ 2^14 and W_lo stays a NORMAL fp16
+                float mx = 0.f;
+                for (float v : w) mx = std::max(mx, std::fabs(v));
+                int sh = 0;
+                while (sh < 24 && mx > 0.f && mx * 2.f <= 16384.f) { mx *= 2.f; ++sh; }
+                L.acc_shift = sh;
+                const float f = std::ldexp(1.f, sh);
+                for (float &v : w) v *= f;
+            }
+            for (size_t i = 0; i < w.size(); ++i) {
+                const _Float16 hi = (_Float16)w[i];
+                // split layers: packed index k of the third plane carries the residue W - fp16(W)
+                wh[i] = (lo_plane && (*lo_plane)[i % (size_t)L.Kpad]) ? (_Float16)(w[i] - (float)hi) : hi;
+            }
             L.w = static_cast<float *>(upload_bytes(wh.data(), wh.size() * sizeof(_Float16)));
         } else {
             L.w = upload(w);
@@ -320,12 +338,15 @@ struct Loader {
         const bool has_bn = !bn.empty();
         if (has_bn && !bn_fold(bn, Cout, sc, sh)) return;
         if (!w || (!bkey.empty() && !cb)) return;
-        const int cp = cin_pad ? cin_pad : Cin;
+        const int plane = cin_pad ? cin_pad : Cin;            // physical channels (per plane when split)
+        const bool sp = split && f16;
+        const int cp = sp ? 3 * plane : plane;                // the channel count the kernel's K order walks
         const float *wd = w->data.data();
+        const bool chunked = cp % (f16 ? 64 : 32) == 0 && (!sp || plane % 64 == 0);
         auto wt = [=](int o, int k) -> float {
             int c, tap;
             const int CH = f16 ? 64 : 32;
-            if (cp % CH == 0) {   // K order (chunk, r, s, c % CH), CH = 32 (fp32) / 64 (fp16): conv_igemm.hip
+            if (chunked) {   // K order (chunk, r, s, c % CH), CH = 32 (fp32) / 64 (fp16): conv_igemm.hip
                 const int chunk = k / (CH * R * S), rem = k % (CH * R * S);
                 tap = rem / CH;
                 c = chunk * CH + rem % CH;
@@ -333,10 +354,22 @@ struct Loader {
                 c = k % cp;
                 tap = k / cp;
             }
+            if (sp) c %= plane;   // virtual channel -> channel; which plane it is only decides hi / lo (lo_plane below)
             if (c >= Cin) return 0.f;
             return wd[(((size_t)o * Cin + c) * R + tap / S) * S + tap % S];
         };
-        if (rd && R == 3 && S == 3 && !cb) {
+        std::vector<unsigned char> lo_plane;
+        if (sp) {   // packed indices whose virtual channel lies in the third plane
+            const int K = R * S * cp, Kp = round_up(K, 64), CH = 64;
+            lo_plane.assign(Kp, 0);
+            for (int k = 0; k < K; ++k) {
+                int c;
+                if (chunked) { const int chunk = k / (CH * R * S), rem = k % (CH * R * S); c = chunk * CH + rem % CH; }
+                else c = k % cp;
+                lo_plane[k] = c / plane == 2;
+            }
+        }
+        if (rd && R == 3 && S == 3 && !cb && !sp) {
             // row-decomposed packing: GEMM output o' = (s, n), reduction k = (r, c); bias / BN shift live in group s = 0
             const int CH = f16 ? 64 : 32;
             auto wt3 = [=](int o2, int k) -> float {
@@ -364,8 +397,9 @@ struct Loader {
             return;
         }
         finish(L, label, cp, Cout, R, S, R * S * cp, wt, has_bn ? &sc : nullptr, has_bn ? &sh : nullptr,
-               cb ? cb->data.data() : nullptr, f16);
+               cb ? cb->data.data() : nullptr, f16, sp ? &lo_plane : nullptr);
         L.Kreal = R * S * Cin;
+        if (sp) L.plane = plane;
     }
 
     // nn.Linear weight [out][in] (+ optional bias)
@@ -404,7 +438,8 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     if (cfg->backbone < HMV_RESNET18 || cfg->backbone > HMV_HRNET_W64) return bad("Supports only 18, 34, 50_paper (resnet) and w40, w64 (hrnet)");
     if (cfg->num_views < 1 || cfg->num_views > 48) return bad("num_views must be in [1, 48]");
     if (cfg->fusion_layers < 1 || cfg->fusion_layers % 2 != 1) return bad("num_layers must be an odd number");
-    if (cfg->dtype != HMV_F32 && cfg->dtype != HMV_F16) { g_create_err = "dtype must be HMV_F32 or HMV_F16"; return HMV_ERR_UNSUPPORTED; }
+    if (cfg->dtype != HMV_F32 && cfg->dtype != HMV_F16 && cfg->dtype != HMV_F32X3) { g_create_err = "dtype must be HMV_F32, HMV_F16 or HMV_F32X3"; return HMV_ERR_UNSUPPORTED; }
+    if (cfg->dtype == HMV_F32X3 && cfg->backbone != HMV_RESNET50_PAPER) { g_create_err = "HMV_F32X3 is built for the ResNet50-paper backbone only"; return HMV_ERR_UNSUPPORTED; }
     if (cfg->height < 32 || cfg->width < 32 || cfg->height % 32 || cfg->width % 32)
         return bad("frame height/width must be positive multiples of 32");
     if (cfg->image_size <= 0 || cfg->heatmap_size <= 0) return bad("image_size / heatmap_size must be positive");
@@ -454,7 +489,8 @@ int hmv_finalize_weights(hmv_handle h) {
     Loader L{h};
     const hmv_config &c = h->cfg;
     const int exp = h->paper ? 4 : 1;
-    const bool h16 = c.dtype == HMV_F16;   // conv stack in fp16; heat-map logits, tokens, fusion, decoder stay fp32
+    const bool h16 = c.dtype != HMV_F32;   // conv stack on the fp16 kernels; heat-map logits, tokens, fusion, decoder stay fp32
+    L.split = c.dtype == HMV_F32X3;        // ... with (hi, lo) pairs: fp32-equivalent
 
     if (h->hrnet) {
         // ---- HighResolutionNet: hrnet.py:231-311.  Every tensor keeps its real channel stride (dense-K conv mode for 40 / 80 channels).
@@ -821,7 +857,15 @@ struct Runner {
         p.scatter = scatter; p.osy = scatter ? 2 : 1; p.osx = scatter ? 2 : 1; p.ooy = ooy; p.oox = oox;
         p.up = up; p.fill = fill ? 1 : 0;
         if (L.rd_cout) { p.rd_cout = L.rd_cout; p.pad_w = 0; }   // L.R x L.S is the 3x1 GEMM, the epilogue sums the s groups
-        const ConvTile tile = conv_pick_tile(p.M, p.Cout, p.K, L.f16, res != nullptr);
+        if (L.plane) {   // HMV_F32X3: [hi | lo] rows in, pairs out (unless this layer writes fp32), pairs as residual
+            p.lda = 2 * L.plane;
+            p.cwrap = 2 * L.plane;
+            p.acc_shift = L.acc_shift;
+            if (out_f16) { p.out_split = 1; p.ldc = 2 * ldc; }
+            if (res) { p.res_split = 1; p.ldr = 2 * ldr; }
+        }
+        // split layers walk 3x the reduction on fp16 MFMAs: the tile rules see the real reduction length
+        const ConvTile tile = conv_pick_tile(p.M, p.Cout, L.plane ? p.K / 3 : p.K, L.f16, res != nullptr);
         ProfRec *pr = nullptr;
         if (h->profiling) {
             if (h->prof_used == h->prof.size()) {
@@ -859,8 +903,9 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     const int d = h->d, ldt = h->ldt;
     // fp16 path: the conv stack (stem .. pose_net / sample convs) stores activations as fp16; heat-map logits,
     // coordinates, tokens, fusion and decoder stay fp32.  ACT(n) = arena floats for n activation elements.
-    const bool h16 = c.dtype == HMV_F16;
-#define ACT(n) ((h16) ? ((size_t)(n) + 1) / 2 : (size_t)(n))
+    const bool h16 = c.dtype != HMV_F32;      // the conv stack runs on the fp16 kernels ...
+    const bool split = c.dtype == HMV_F32X3;  // ... on (hi, lo) pairs: 4 bytes per element like fp32
+#define ACT(n) ((h16 && !split) ? ((size_t)(n) + 1) / 2 : (size_t)(n))
 #define LAUNCH(expr) do { if (!dry && R.rc == HMV_OK) R.check((expr), #expr); } while (0)
 
     // sampled feature levels in the reference's feats[] order (handmvnet.py:165-177), channels-last with row stride ld
@@ -872,7 +917,7 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         // ================= HighResolutionNet.forward (hrnet.py:357-393) =================
         const HrNet &hr = h->hr;
         float *in4 = R.alloc((size_t)N * H * W * 4);
-        if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, h16, in4, s));
+        if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, h16 ? 1 : 0, in4, s));
         else if (h16) LAUNCH(launch_nchw_to_nhwc8_f16(x, in4, N, H, W, s));
         else LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
         const int H1 = (H + 2 - 3) / 2 + 1, W1 = (W + 2 - 3) / 2 + 1, H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
@@ -1013,8 +1058,10 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         R.conv(h->pose0, lvl[0], N, lvh[0], lvw[0], 2, 1, 1, hm, 32, nullptr, 0, ACT_NONE, hmh, hmw);
     } else {
     // ---- stem: conv1 7x7 s2 + BN + ReLU, maxpool 3x3 s2 (resnet.py:218-221)
-    float *in4 = R.alloc((size_t)N * H * W * 4);   // NHWC4 fp32 and NHWC8 fp16 are both 16 bytes per pixel
-    if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, h16, in4, s));
+    // NHWC4 fp32 and NHWC8 fp16 are both 16 bytes per pixel; split pairs [hi8 | lo8] take 32
+    float *in4 = R.alloc((size_t)N * H * W * (split ? 8 : 4));
+    if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, split ? 2 : (h16 ? 1 : 0), in4, s));
+    else if (split) LAUNCH(launch_nchw_to_nhwc_split(x, in4, N, H, W, s));
     else if (h16) LAUNCH(launch_nchw_to_nhwc8_f16(x, in4, N, H, W, s));
     else LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
     const int H1 = (H + 6 - 7) / 2 + 1, W1 = (W + 6 - 7) / 2 + 1;
@@ -1023,7 +1070,8 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     R.release(in4);
     int hh = (H1 + 2 - 3) / 2 + 1, ww = (W1 + 2 - 3) / 2 + 1, C = 64;
     float *cur = R.alloc(ACT((size_t)N * hh * ww * 64));
-    if (h16) LAUNCH(launch_maxpool3s2_f16(c1, cur, N, H1, W1, 64, hh, ww, s));
+    if (split) LAUNCH(launch_maxpool3s2_split(c1, cur, N, H1, W1, 64, hh, ww, s));
+    else if (h16) LAUNCH(launch_maxpool3s2_f16(c1, cur, N, H1, W1, 64, hh, ww, s));
     else LAUNCH(launch_maxpool3s2(c1, cur, N, H1, W1, 64, hh, ww, s));
     R.release(c1);
 
@@ -1085,7 +1133,8 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     float *feat0 = level[2];
     const int fh = lh[2], fw = lw[2];
     if (h->capture && !dry && h->cap_feat0) {
-        if (h16) LAUNCH(launch_nhwc_f16_to_nchw(feat0, h->cap_feat0, N, fh, fw, lc[2], s));
+        if (split) LAUNCH(launch_nhwc_split_to_nchw(feat0, h->cap_feat0, N, fh, fw, lc[2], s));
+        else if (h16) LAUNCH(launch_nhwc_f16_to_nchw(feat0, h->cap_feat0, N, fh, fw, lc[2], s));
         else LAUNCH(launch_nhwc_to_nchw(feat0, h->cap_feat0, N, fh, fw, lc[2], s));
     }
 
@@ -1131,7 +1180,8 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     for (int i = 0; i < c.n_levels; ++i) {
         const int Ci = lvld[i], co = lvc[i] / 2;   // gather the (padded) channel rows; the conv's pad weights are zero
         float *g = R.alloc(ACT((size_t)N * NJ * 4 * Ci));
-        LAUNCH(launch_sample_gather(lvl[i], N, lvh[i], lvw[i], Ci, coords, g, s, h16 ? 2 : 4));
+        // a split row is Ci (hi, lo) pairs = Ci 4-byte elements, like fp32
+        LAUNCH(launch_sample_gather(lvl[i], N, lvh[i], lvw[i], Ci, coords, g, s, (h16 && !split) ? 2 : 4));
         float *s4 = R.alloc((size_t)N * NJ * 4 * co);
         R.gemm(h->sample[i], g, N * NJ * 4, s4, co, nullptr, 0, ACT_RELU);
         R.release(g);
@@ -1388,7 +1438,7 @@ int hmv_op_prepare_frames(int32_t device, const uint8_t *frames, int32_t n_frame
     if (!frames || !crop_boxes || !mean || !std || !out_nhwc4 || n_frames <= 0 || frame_h <= 0 || frame_w <= 0 || out_h <= 0 || out_w <= 0)
         return HMV_ERR_ARG;
     if (hipSetDevice(device) != hipSuccess) return HMV_ERR_HIP;
-    return launch_frames_to_input(frames, crop_boxes, n_frames, frame_h, frame_w, out_h, out_w, mean, std, false, out_nhwc4,
+    return launch_frames_to_input(frames, crop_boxes, n_frames, frame_h, frame_w, out_h, out_w, mean, std, 0, out_nhwc4,
                                   static_cast<hipStream_t>(stream)) == hipSuccess ? HMV_OK : HMV_ERR_HIP;
 }
 

@@ -36,6 +36,13 @@ struct ConvParams {
     const float *zero;  // 256 bytes of zeros (filled in by launch_conv)
     int cpt;            // dense mode: 16-byte vectors per tap (Cin / 4, or Cin / 8 in fp16); filled in by launch_conv
     unsigned cpt_magic, s_magic;   // ceil(2^32 / cpt), ceil(2^32 / S): exact division by multiply-high for k indices < 2^16
+    // fp32-equivalent "split" operands on the fp16 kernels (HMV_F32X3): a tensor row is [hi plane | lo plane] of fp16
+    // and the reduction walks the virtual channel sequence hi, lo, hi against weights packed [W_hi | W_hi | W_lo]
+    int cwrap;          // physical channels per pixel (2 * C): a virtual channel offset >= cwrap wraps back to the hi plane (0 = off)
+    int res_split;      // residual rows are [hi | lo] pairs (plane stride ldr / 2): value = hi + lo
+    int acc_shift;      // split layers: the packed weights are W * 2^acc_shift (keeps W_lo out of the fp16 subnormals);
+    float acc_scale;    //   the epilogue multiplies the accumulator by 2^-acc_shift (filled in by launch_conv)
+    int out_split;      // write (hi, lo) pairs (plane stride ldc / 2) instead of one fp16 value
     int rd_cout;        // row-decomposed 3x3 (narrow Cout): the real channel count; Cout is then 3 * rd_cout, R = 3, S = 1
     int lda;            // input pixel stride in floats (0 = Cin)
     int ldw;            // weight row stride in floats (0 = Kpad)
@@ -67,8 +74,13 @@ hipError_t launch_sample_gather(const float *feat, int N, int H, int W, int C, c
 // fp16 path (BASELINE configs[4])
 hipError_t launch_nchw_to_nhwc8_f16(const float *x, void *out, int N, int H, int W, hipStream_t s);
 // uint8 HWC camera frames + integer crop windows -> normalised NHWC4 fp32 / NHWC8 fp16 stem input (ho3d.py:35-40, 136-149)
+// out_mode: 0 = NHWC4 fp32, 1 = NHWC8 fp16, 2 = split [hi8 | lo8] fp16 pairs (HMV_F32X3)
 hipError_t launch_frames_to_input(const uint8_t *frames, const int *boxes, int N, int Hf, int Wf, int S_h, int S_w, const float *mean,
-                                  const float *std, bool f16, void *out, hipStream_t s);
+                                  const float *std, int out_mode, void *out, hipStream_t s);
+// HMV_F32X3 helpers: tensors whose rows are [hi plane | lo plane] fp16 pairs
+hipError_t launch_nchw_to_nhwc_split(const float *x, void *out, int N, int H, int W, hipStream_t s);
+hipError_t launch_maxpool3s2_split(const void *in, void *out, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
+hipError_t launch_nhwc_split_to_nchw(const void *in, float *out, int N, int H, int W, int C, hipStream_t s);
 hipError_t launch_maxpool3s2_f16(const void *in, void *out, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 hipError_t launch_nhwc_f16_to_nchw(const void *in, float *out, int N, int H, int W, int C, hipStream_t s);
 // tokens[(n*21+j)][col0 + c] = sum_t w_t * s[(n*21+j)*4+t][c]

@@ -93,6 +93,105 @@ hipError_t launch_maxpool3s2_f16(const void *in, void *out, int N, int H, int W,
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ HMV_F32X3: fp32 values as (hi, lo) fp16 pairs
+// A tensor row is [hi plane (C halfs) | lo plane (C halfs)]: hi = fp16(v), lo = fp16(v - hi); hi + lo == v to ~2^-22.
+__device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
+    const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+    hi = (_Float16)c;
+    lo = (_Float16)(c - (float)hi);
+}
+// frames NCHW fp32 -> per pixel [hi: r g b 0 0 0 0 0 | lo: r g b 0 0 0 0 0] (32 bytes)
+__global__ void nchw_to_nhwc_split_kernel(const float *__restrict__ x, f16x8 *__restrict__ out, int HW, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const size_t n = i / HW, pix = i - n * HW;
+        const float *src = x + n * 3 * (size_t)HW + pix;
+        f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            _Float16 a, b;
+            split_f16(src[c * (size_t)HW], a, b);
+            h[c] = a; l[c] = b;
+        }
+        out[2 * i] = h;
+        out[2 * i + 1] = l;
+    }
+}
+hipError_t launch_nchw_to_nhwc_split(const float *x, void *out, int N, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)N * H * W;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(nchw_to_nhwc_split_kernel, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<f16x8 *>(out), H * W, total);
+    return hipGetLastError();
+}
+// MaxPool2d(3, 2, 1) on split tensors: the maximum of the reconstructed values, re-split
+__global__ void maxpool3s2_split_kernel(const f16x8 *__restrict__ in, f16x8 *__restrict__ out, int H, int W, int C8, int Ho,
+                                        int Wo, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % C8);
+        size_t t = i / C8;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const size_t n = t / Ho;
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = ho * 2 - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int wi = wo * 2 - 1 + q;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f16x8 *px = in + ((n * H + hi) * W + wi) * (size_t)(2 * C8);
+                const f16x8 h = px[c], l = px[C8 + c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)h[j] + (float)l[j]);
+            }
+        }
+        f16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 a, b;
+            split_f16(m[j], a, b);
+            h[j] = a; l[j] = b;
+        }
+        f16x8 *o = out + (i / C8) * (size_t)(2 * C8);
+        o[c] = h;
+        o[C8 + c] = l;
+    }
+}
+hipError_t launch_maxpool3s2_split(const void *in, void *out, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool3s2_split_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const f16x8 *>(in),
+                       reinterpret_cast<f16x8 *>(out), H, W, C / 8, Ho, Wo, total);
+    return hipGetLastError();
+}
+// split NHWC -> NCHW fp32 (stage capture)
+__global__ void nhwc_split_to_nchw_kernel(const _Float16 *__restrict__ in, float *__restrict__ out, int HW, int C, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int p = (int)(i % HW);
+        const size_t t = i / HW;
+        const int c = (int)(t % C);
+        const size_t n = t / C;
+        const _Float16 *px = in + (n * HW + p) * (size_t)(2 * C);
+        out[i] = (float)px[c] + (float)px[C + c];
+    }
+}
+hipError_t launch_nhwc_split_to_nchw(const void *in, float *out, int N, int H, int W, int C, hipStream_t s) {
+    const size_t total = (size_t)N * H * W * C;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nhwc_split_to_nchw_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const _Float16 *>(in), out, H * W, C, total);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ MaxPool2d(3, stride 2, pad 1), NHWC
 // resnet.py:165,221
 __global__ void maxpool3s2_kernel(const f32x4 *__restrict__ in, f32x4 *__restrict__ out, int H, int W, int C4, int Ho,
@@ -584,7 +683,8 @@ __device__ __forceinline__ void aa_span(int o, int in_size, float scale, float &
     count = min((int)(center + support + 0.5f), in_size) - first;
 }
 
-template <bool F16>
+// OUT: 0 = NHWC4 fp32, 1 = NHWC8 fp16, 2 = split [hi8 | lo8] fp16 pairs (HMV_F32X3)
+template <int OUT>
 __global__ void frames_to_input_kernel(const uint8_t *__restrict__ frames, const int *__restrict__ boxes, int Hf, int Wf, int S_h,
                                        int S_w, FrameNorm nm, void *__restrict__ out, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -633,7 +733,15 @@ __global__ void frames_to_input_kernel(const uint8_t *__restrict__ frames, const
         }
         const float r = (acc[0] - nm.mean[0]) * nm.inv_std[0], g = (acc[1] - nm.mean[1]) * nm.inv_std[1],
                     b = (acc[2] - nm.mean[2]) * nm.inv_std[2];
-        if (F16) {
+        if (OUT == 2) {
+            f16x8 hv = {0, 0, 0, 0, 0, 0, 0, 0}, lv = {0, 0, 0, 0, 0, 0, 0, 0};
+            _Float16 a, c;
+            split_f16(r, a, c); hv[0] = a; lv[0] = c;
+            split_f16(g, a, c); hv[1] = a; lv[1] = c;
+            split_f16(b, a, c); hv[2] = a; lv[2] = c;
+            reinterpret_cast<f16x8 *>(out)[2 * i] = hv;
+            reinterpret_cast<f16x8 *>(out)[2 * i + 1] = lv;
+        } else if (OUT == 1) {
             f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             v[0] = (_Float16)r; v[1] = (_Float16)g; v[2] = (_Float16)b;
             reinterpret_cast<f16x8 *>(out)[i] = v;
@@ -643,13 +751,14 @@ __global__ void frames_to_input_kernel(const uint8_t *__restrict__ frames, const
     }
 }
 hipError_t launch_frames_to_input(const uint8_t *frames, const int *boxes, int N, int Hf, int Wf, int S_h, int S_w, const float *mean,
-                                  const float *std, bool f16, void *out, hipStream_t s) {
+                                  const float *std, int out_mode, void *out, hipStream_t s) {
     FrameNorm nm;
     for (int c = 0; c < 3; ++c) { nm.mean[c] = mean[c]; nm.inv_std[c] = 1.f / std[c]; }
     const size_t total = (size_t)N * S_h * S_w;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (f16) hipLaunchKernelGGL(frames_to_input_kernel<true>, dim3(grid), dim3(256), 0, s, frames, boxes, Hf, Wf, S_h, S_w, nm, out, total);
-    else hipLaunchKernelGGL(frames_to_input_kernel<false>, dim3(grid), dim3(256), 0, s, frames, boxes, Hf, Wf, S_h, S_w, nm, out, total);
+    if (out_mode == 2) hipLaunchKernelGGL(frames_to_input_kernel<2>, dim3(grid), dim3(256), 0, s, frames, boxes, Hf, Wf, S_h, S_w, nm, out, total);
+    else if (out_mode == 1) hipLaunchKernelGGL(frames_to_input_kernel<1>, dim3(grid), dim3(256), 0, s, frames, boxes, Hf, Wf, S_h, S_w, nm, out, total);
+    else hipLaunchKernelGGL(frames_to_input_kernel<0>, dim3(grid), dim3(256), 0, s, frames, boxes, Hf, Wf, S_h, S_w, nm, out, total);
     return hipGetLastError();
 }
 

@@ -51,7 +51,7 @@ class HandMvNet(torch.nn.Module):
         # the reference constructor random-initialises; ours does so deterministically
         self._weights: "OrderedDict[str, np.ndarray]" = synth_state_dict(self.cfg, init_seed)
         self._engines: Dict[tuple, ctypes.c_void_p] = {}
-        self._dtype = 0   # 0 = fp32 (HMV_F32), 1 = fp16 conv stack (HMV_F16, BASELINE configs[4])
+        self._dtype = 0   # 0 = fp32 (HMV_F32), 1 = fp16 conv stack (HMV_F16, BASELINE configs[4]), 2 = split fp16 pairs (HMV_F32X3)
         self._capture = False
         self._profiling = False
         self._graphs = None   # None: the engine's default (off unless HMV_GRAPHS=1)
@@ -102,6 +102,14 @@ class HandMvNet(torch.nn.Module):
     def float(self):
         if self._dtype != 0:
             self._dtype = 0
+            self._drop_engines()
+        return self
+
+    def float32x3(self):
+        """fp32-equivalent arithmetic on the fp16 matrix cores (HMV_F32X3, ResNet50-paper only): every value of the conv
+        stack travels as a (hi, lo) fp16 pair and every product is hi*hi + lo*hi + hi*lo with fp32 accumulation."""
+        if self._dtype != 2:
+            self._dtype = 2
             self._drop_engines()
         return self
 

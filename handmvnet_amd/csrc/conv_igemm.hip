@@ -37,6 +37,7 @@
 //     through LDS so that global traffic is 16-byte vectors on full output rows.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
                     *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out) + (size_t)m * p.ldc + 4 * c4) = t;
             }
         } else if (vec) {
+            if constexpr (!F16) {   // the fp32 kernels keep their hand-tuned 4-wide drain (any restructuring here costs ~3 %)
             constexpr int TPR = BN / 4, RPP = NT / TPR, NPASS = SR / RPP, UB = NPASS < HMV_UB ? NPASS : HMV_UB;
             static_assert(SR % RPP == 0 && NPASS % UB == 0, "staging pass shape");
             const int c4 = tid % TPR, r0 = tid / TPR;
@@ -451,6 +453,127 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
                         }
                     }
                 }
+            }
+            } else {
+            // W output columns per thread: 4 (one 16-byte fp32 vector) or, for 16-bit outputs of the fp16 kernels, 8 (so that
+            // fp16 / (hi, lo) rows are written and fp16 residuals read as 16-byte vectors too: 8-byte accesses capped the
+            // residual-bearing fp16 layers at ~3 TB/s)
+            auto drain = [&](auto wtag) {
+                constexpr int W = decltype(wtag)::value, W4 = W / 4;
+                constexpr int TPR = BN / W, RPP = NT / TPR, NPASS = SR / RPP, UB = NPASS < HMV_UB ? NPASS : HMV_UB;
+                static_assert(SR % RPP == 0 && NPASS % UB == 0, "staging pass shape");
+                const int cw = tid % TPR, r0 = tid / TPR;
+                const int col = n0 + W * cw;
+                // columns [Cout, round4(Cout)) hold exact zeros (zero-padded weights and bias): writing them is
+                // harmless whenever the row stride leaves room, which lets Cout = 21 use vector stores too.
+                const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + W - 1) & ~(W - 1));
+                if (col >= cend) return;
+                f32x4 bv[W4];
+#pragma unroll
+                for (int q = 0; q < W4; ++q) bv[q] = *reinterpret_cast<const f32x4 *>(p.bias + col + 4 * q);
+                const bool has_res = p.res != nullptr;
+                const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+#pragma unroll
+                for (int g = 0; g < NPASS; g += UB) {
+                    f32x4 v[UB][W4], rv[UB][W4];
+                    size_t orow[UB];
+                    bool okr[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int sr = r0 + (g + u) * RPP, m = mt * BM + tile_row(sr);
+                        okr[u] = m < p.M;
+                        orow[u] = (size_t)m;
+                        size_t rrow = (size_t)m;
+                        if (GENERIC) {
+                            if (p.scatter) orow[u] = out_row(m);
+                            if (p.rg_out) rrow = (size_t)(m / p.rg_out) * p.rg_in + (m % p.rg_out);
+                        }
+                        if (p.res_f16) {   // fp16 residual (the zero page stands in for "no residual" / rows past M)
+                            const bool live = has_res && okr[u];
+                            const _Float16 *rp = live ? reinterpret_cast<const _Float16 *>(p.res) + rrow * p.ldr + col
+                                                      : reinterpret_cast<const _Float16 *>(p.zero);
+#pragma unroll
+                            for (int q = 0; q < W4; ++q) {
+                                const f16x4 hv = *reinterpret_cast<const f16x4 *>(rp + 4 * q);
+                                rv[u][q] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                            }
+                            if (p.res_split) {   // [hi | lo] pair: the lo plane sits ldr / 2 further
+                                const _Float16 *lp = live ? rp + (p.ldr >> 1) : rp;
+#pragma unroll
+                                for (int q = 0; q < W4; ++q) {
+                                    const f16x4 lv = *reinterpret_cast<const f16x4 *>(lp + 4 * q);
+                                    rv[u][q] += f32x4{(float)lv[0], (float)lv[1], (float)lv[2], (float)lv[3]};
+                                }
+                            }
+                        } else {
+                            const float *rp = (has_res && okr[u]) ? reinterpret_cast<const float *>(p.res) + rrow * p.ldr + col : p.zero;
+#pragma unroll
+                            for (int q = 0; q < W4; ++q) rv[u][q] = *reinterpret_cast<const f32x4 *>(rp + 4 * q);
+                        }
+#pragma unroll
+                        for (int q = 0; q < W4; ++q) v[u][q] = *reinterpret_cast<const f32x4 *>(&sC[sr * LDC + W * cw + 4 * q]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        f32x4 t[W4];
+#pragma unroll
+                        for (int q = 0; q < W4; ++q) {
+                            t[q] = v[u][q] + bv[q] + rv[u][q];
+                            if constexpr (F16) t[q] = v[u][q] * p.acc_scale + bv[q] + rv[u][q];   // 1.0 unless the weights were pre-scaled
+                            if (GENERIC) {
+                                if (p.act == ACT_GELU) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) t[q][j] = 0.5f * t[q][j] * (1.f + erff(t[q][j] * 0.70710678118654752440f));
+                                } else if (p.act == ACT_LEAKY) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) t[q][j] = t[q][j] > 0.f ? t[q][j] : 0.01f * t[q][j];
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) t[q][j] = fmaxf(t[q][j], lo);
+                        }
+                        if (!okr[u]) continue;
+                        if (p.out_split) {   // fp32 value -> (hi, lo) fp16 pair, hi + lo == value to ~2^-22
+                            _Float16 hv[W], lv[W];
+#pragma unroll
+                            for (int j = 0; j < W; ++j) {
+                                const float c = fminf(fmaxf(t[j >> 2][j & 3], -65504.f), 65504.f);
+                                hv[j] = (_Float16)c;
+                                lv[j] = (_Float16)(c - (float)hv[j]);
+                            }
+                            _Float16 *op = reinterpret_cast<_Float16 *>(p.out) + orow[u] * p.ldc + col;
+                            if constexpr (W == 8) {
+                                *reinterpret_cast<f16x8 *>(op) = f16x8{hv[0], hv[1], hv[2], hv[3], hv[4], hv[5], hv[6], hv[7]};
+                                *reinterpret_cast<f16x8 *>(op + (p.ldc >> 1)) = f16x8{lv[0], lv[1], lv[2], lv[3], lv[4], lv[5], lv[6], lv[7]};
+                            } else {
+                                *reinterpret_cast<f16x4 *>(op) = f16x4{hv[0], hv[1], hv[2], hv[3]};
+                                *reinterpret_cast<f16x4 *>(op + (p.ldc >> 1)) = f16x4{lv[0], lv[1], lv[2], lv[3]};
+                            }
+                        } else if (p.out_f16) {
+                            _Float16 *op = reinterpret_cast<_Float16 *>(p.out) + orow[u] * p.ldc + col;
+                            if constexpr (W == 8)
+                                *reinterpret_cast<f16x8 *>(op) = f16x8{(_Float16)t[0][0], (_Float16)t[0][1], (_Float16)t[0][2], (_Float16)t[0][3],
+                                                                       (_Float16)t[W4 - 1][0], (_Float16)t[W4 - 1][1], (_Float16)t[W4 - 1][2], (_Float16)t[W4 - 1][3]};
+                            else
+                                *reinterpret_cast<f16x4 *>(op) = f16x4{(_Float16)t[0][0], (_Float16)t[0][1], (_Float16)t[0][2], (_Float16)t[0][3]};
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < W4; ++q)
+                                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out) + orow[u] * p.ldc + col + 4 * q) = t[q];
+                        }
+                    }
+                }
+            };
+            bool wide = false;
+            if constexpr (F16 && !GENERIC && BN % 8 == 0 && (NT % (BN / 8)) == 0)
+                wide = (p.out_f16 || p.out_split) && ((p.out_split ? p.ldc >> 1 : p.ldc) & 7) == 0 &&
+                       (p.res == nullptr || ((p.res_split ? p.ldr >> 1 : p.ldr) & 7) == 0);
+            if constexpr (F16 && !GENERIC && BN % 8 == 0 && (NT % (BN / 8)) == 0) {
+                if (wide) drain(std::integral_constant<int, 8>{});
+                else drain(std::integral_constant<int, 4>{});
+            } else {
+                drain(std::integral_constant<int, 4>{});
+            }
             }
         } else if (GENERIC) {   // scalar fallback (row strides that are not multiples of 4, e.g. the 21x3 output)
             for (int idx = tid; idx < SR * BN; idx += NT) {

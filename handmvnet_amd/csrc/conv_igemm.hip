@@ -651,7 +651,7 @@ bool conv_partial_n(ConvTile t, int Cout) {
     return (Cout + bn - 1) / bn * bn - Cout >= 32;
 }
 
-ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
+ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool /*has_res*/) {
     static int forced = -2;   // development knob: HMV_FORCE_TILE=<ConvTile> for layers with Cout > 64
     if (forced == -2) { const char *e = getenv("HMV_FORCE_TILE"); forced = e ? atoi(e) : -1; }
     if (Cout > 64 && forced >= 0 && forced < TILE_COUNT) return (ConvTile)forced;
@@ -659,11 +659,9 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
     // the least L2->LDS traffic per FLOP wins as long as it still fills the 256 CUs for several rounds.
     // tiny-K expanding convs (layer1/2 conv3 + residual) are epilogue/HBM-bound: 4 small blocks per CU
     // overlap one block's residual read / store with the others' short main loops
-    if (Cout >= 256 && K <= 128 && M >= 65536) return TILE_128x128_K16;
-    // fp16: the main loop of a residual-bearing expanding 1x1 conv is so short (K = 256: 4 k-steps) that the single
-    // 256x256 block per CU spends 3/4 of its life in the epilogue; 4 small blocks per CU overlap it (0.61 -> 0.47 ms on
-    // layer3 conv3, forced-tile A/B runs of bench.py --dtype f16 --per-layer)
-    if (f16 && has_res && Cout >= 256 && K <= 256 && M >= 65536) return TILE_128x128_K16;
+    // fp32 only: with 16-byte vectors on both sides of the fp16 epilogue the big tile wins there too (forced-tile
+    // A/B runs of bench.py --dtype f16 / f32x3 --per-layer)
+    if (!f16 && Cout >= 256 && K <= 128 && M >= 65536) return TILE_128x128_K16;
     // channel counts that are not multiples of 128 (HRNet-w40: 160, 320), measured with tools/hr_sweep.py: one 256-wide
     // N-tile with its all-padding blocks skipped beats two 128-wide tiles whose second one is mostly DMA latency;
     // 64-wide tiles beat 128-wide ones when the last 128-wide tile would be at most half real.

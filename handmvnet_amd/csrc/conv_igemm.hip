@@ -466,7 +466,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
                 const int col = n0 + W * cw;
                 // columns [Cout, round4(Cout)) hold exact zeros (zero-padded weights and bias): writing them is
                 // harmless whenever the row stride leaves room, which lets Cout = 21 use vector stores too.
-                const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + W - 1) & ~(W - 1));
+                const int rowc = p.out_split ? p.ldc >> 1 : p.ldc;   // columns of one plane / of the row
+                const int cend = (p.fill || p.Cout + 3 >= rowc) ? rowc : ((p.Cout + W - 1) & ~(W - 1));
                 if (col >= cend) return;
                 f32x4 bv[W4];
 #pragma unroll

@@ -439,7 +439,10 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     if (cfg->num_views < 1 || cfg->num_views > 48) return bad("num_views must be in [1, 48]");
     if (cfg->fusion_layers < 1 || cfg->fusion_layers % 2 != 1) return bad("num_layers must be an odd number");
     if (cfg->dtype != HMV_F32 && cfg->dtype != HMV_F16 && cfg->dtype != HMV_F32X3) { g_create_err = "dtype must be HMV_F32, HMV_F16 or HMV_F32X3"; return HMV_ERR_UNSUPPORTED; }
-    if (cfg->dtype == HMV_F32X3 && cfg->backbone != HMV_RESNET50_PAPER) { g_create_err = "HMV_F32X3 is built for the ResNet50-paper backbone only"; return HMV_ERR_UNSUPPORTED; }
+    if (cfg->dtype == HMV_F32X3 && cfg->backbone != HMV_RESNET50_PAPER && cfg->backbone < HMV_HRNET_W40) {
+        g_create_err = "HMV_F32X3 is built for the ResNet50-paper and HRNet backbones only";
+        return HMV_ERR_UNSUPPORTED;
+    }
     if (cfg->height < 32 || cfg->width < 32 || cfg->height % 32 || cfg->width % 32)
         return bad("frame height/width must be positive multiples of 32");
     if (cfg->image_size <= 0 || cfg->heatmap_size <= 0) return bad("image_size / heatmap_size must be positive");
@@ -499,7 +502,7 @@ int hmv_finalize_weights(hmv_handle h) {
         for (int i = 0; i < 4; ++i) hr.ch[i] = kHrChannels[c.backbone - HMV_HRNET_W40][i];
         // the highest-resolution branch (H/4 x W/4) of w40 has 40 channels: its stride-1 3x3 convs run row-decomposed
         // when a 128-row tile covers whole image rows (conv_igemm.hip, RD)
-        const bool rd0 = 3 * hr.ch[0] <= 128 && hr.ch[0] % 4 == 0 && 128 % (c.width / 4) == 0 && !getenv("HMV_NO_ROWSUM");
+        const bool rd0 = 3 * hr.ch[0] <= 128 && hr.ch[0] % 4 == 0 && 128 % (c.width / 4) == 0 && !L.split && !getenv("HMV_NO_ROWSUM");
         L.conv(hr.conv1, "stem.conv1", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 3, 3, /*cin_pad=*/h16 ? 8 : 4, h16);
         L.conv(hr.conv2, "stem.conv2", "backbone.conv2.weight", "", "backbone.bn2", 64, 64, 3, 3, 0, h16);
         int inpl_ = 64;
@@ -916,8 +919,9 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     if (h->hrnet) {
         // ================= HighResolutionNet.forward (hrnet.py:357-393) =================
         const HrNet &hr = h->hr;
-        float *in4 = R.alloc((size_t)N * H * W * 4);
-        if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, h16 ? 1 : 0, in4, s));
+        float *in4 = R.alloc((size_t)N * H * W * (split ? 8 : 4));
+        if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, split ? 2 : (h16 ? 1 : 0), in4, s));
+        else if (split) LAUNCH(launch_nchw_to_nhwc_split(x, in4, N, H, W, s));
         else if (h16) LAUNCH(launch_nchw_to_nhwc8_f16(x, in4, N, H, W, s));
         else LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
         const int H1 = (H + 2 - 3) / 2 + 1, W1 = (W + 2 - 3) / 2 + 1, H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
@@ -1049,7 +1053,8 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         nkeep = 4;
         for (int i = 0; i < 4; ++i) { lvl[i] = pre[i]; lvc[i] = hr.ch[i]; lvld[i] = cpad(hr.ch[i]); lvh[i] = preh[i]; lvw[i] = prew[i]; }
         if (h->capture && !dry && h->cap_feat0) {
-            if (h16) LAUNCH(launch_nhwc_f16_to_nchw(lvl[0], h->cap_feat0, N, lvh[0], lvw[0], lvc[0], s));
+            if (split) LAUNCH(launch_nhwc_split_to_nchw(lvl[0], h->cap_feat0, N, lvh[0], lvw[0], lvc[0], s));
+            else if (h16) LAUNCH(launch_nhwc_f16_to_nchw(lvl[0], h->cap_feat0, N, lvh[0], lvw[0], lvc[0], s));
             else LAUNCH(launch_nhwc_to_nchw(lvl[0], h->cap_feat0, N, lvh[0], lvw[0], lvc[0], s, lvld[0]));
         }
         // pose_net = Conv2d(C0, 21, 3, stride 2, padding 1) on the highest-resolution branch (handmvnet.py:51-57, 180)

@@ -233,7 +233,8 @@ def test_fp16_path_within_its_stated_tolerance(name):
 # the real reference, dense stages within 2e-4, coordinates within 0.05 heat-map px (measured: backbone features and heat
 # maps 1e-6, tokens <= 5.5e-5, joints_cam 2e-6 .. 1.6e-4 -- the same as the fp32 engine).
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["tiny_r50", "cfg1_r50_v4_128", "cfg3s_r50_v8_256", "r50_wocam_nn", "r50_odd_96"])
+@pytest.mark.parametrize("name", ["tiny_r50", "cfg1_r50_v4_128", "cfg3s_r50_v8_256", "r50_wocam_nn", "r50_odd_96",
+                                  "hr40_tiny", "hr40_v4_128", "hr64_tiny"])
 def test_split_precision_path_meets_the_fp32_bar(name):
     m, cfg, sd, (x, bbox, intr), fx = _model(name)
     m.float32x3()
@@ -250,9 +251,9 @@ def test_split_precision_path_meets_the_fp32_bar(name):
     assert 0 < d < 2e-5, d
 
 
-def test_split_precision_is_resnet50_only():
+def test_split_precision_is_not_built_for_resnet18():
     from handmvnet_amd import HandMvNet, _lib
     cfg, (tp, mp, dp), sd, (x, bbox, intr), fx = load_case("tiny_r18")
     m = HandMvNet(tp, mp, dp).to("cuda").eval().float32x3()
-    with pytest.raises(_lib.HandMvError, match="ResNet50-paper"):
+    with pytest.raises(_lib.HandMvError, match="ResNet50-paper and HRNet"):
         m(torch.from_numpy(x).cuda(), torch.from_numpy(bbox).cuda(), {"intrinsic": torch.from_numpy(intr).cuda()})

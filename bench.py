@@ -238,6 +238,10 @@ def main():
                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "launches_per_step": d["n"] // max(n_instr, 1), "avg_launch_ms": round(d["ms"] / d["n"], 4),
                     "flops_per_launch": d["flops"] / d["n"]}
+        if args.dtype == "f32x3":   # three fp16 MFMAs per algorithmic multiply-add
+            roofline["executed_tflops"] = round(3 * achieved, 2)
+            roofline["executed_frac"] = round(3 * achieved / peak, 4)
+            roofline["note"] = "achieved counts algorithmic fp32 FLOPs; the fp16 matrix cores execute 3x that (hi*hi + lo*hi + hi*lo)"
         ms_step = elapsed / args.steps * 1e3
         # dense algorithmic count for the ResNet workloads; for HRNet the executed FLOPs of the
         # conv/GEMM launches of one step (the engine's own 2*M*N*K accounting)

@@ -724,7 +724,10 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         tile = TILE_128x128;   // the rarely used epilogue paths exist only for the 4-wave tiles
     const int ch = p.in_f16 ? 64 : 32, epc = p.in_f16 ? 8 : 4;
     const bool dense = p.Cin % ch != 0;
-    if ((p.cwrap || p.res_split || p.out_split || p.acc_shift) && (!p.in_f16 || generic || p.rd_cout)) return hipErrorInvalidValue;
+    // split operands: fp16 kernels only; the generic epilogue handles them on its vector path only
+    if ((p.cwrap || p.res_split || p.out_split || p.acc_shift) &&
+        (!p.in_f16 || p.rd_cout || (p.ldc & 3) || (p.res && (p.ldr & 3)) || p.act == ACT_GELU || p.act == ACT_LEAKY))
+        return hipErrorInvalidValue;
     if (p.rd_cout) {   // row-decomposed 3x3 (see conv_igemm): the caller passes the 3x1 GEMM (R = 3, S = 1, Cout = 3 * rd_cout)
         if (generic || p.R != 3 || p.S != 1 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 0 || p.Cout != 3 * p.rd_cout || p.Cout > 128 ||
             (p.rd_cout & 3) || (p.ldc & 3) || (p.res && (p.ldr & 3)) || 128 % p.Wo != 0 || p.Ho != p.H || p.Wo != p.W)

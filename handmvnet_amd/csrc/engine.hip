@@ -439,10 +439,6 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     if (cfg->num_views < 1 || cfg->num_views > 48) return bad("num_views must be in [1, 48]");
     if (cfg->fusion_layers < 1 || cfg->fusion_layers % 2 != 1) return bad("num_layers must be an odd number");
     if (cfg->dtype != HMV_F32 && cfg->dtype != HMV_F16 && cfg->dtype != HMV_F32X3) { g_create_err = "dtype must be HMV_F32, HMV_F16 or HMV_F32X3"; return HMV_ERR_UNSUPPORTED; }
-    if (cfg->dtype == HMV_F32X3 && cfg->backbone != HMV_RESNET50_PAPER && cfg->backbone < HMV_HRNET_W40) {
-        g_create_err = "HMV_F32X3 is built for the ResNet50-paper and HRNet backbones only";
-        return HMV_ERR_UNSUPPORTED;
-    }
     if (cfg->height < 32 || cfg->width < 32 || cfg->height % 32 || cfg->width % 32)
         return bad("frame height/width must be positive multiples of 32");
     if (cfg->image_size <= 0 || cfg->heatmap_size <= 0) return bad("image_size / heatmap_size must be positive");
@@ -628,13 +624,23 @@ int hmv_finalize_weights(hmv_handle h) {
                 for (int b = 0; b < 2; ++b) {
                     const float *wd = w->data.data();
                     const int CH = h16 ? 64 : 32;
+                    const bool sp = L.split && h16;          // (hi, lo) pairs: the K order walks 3 * c0 virtual channels
+                    const int cv = sp ? 3 * c0 : c0;
                     auto wt = [=](int o, int k) -> float {   // K order (chunk, r, s, c % CH)
                         const int chunk = k / (CH * 4), rem = k % (CH * 4), tap = rem / CH;
-                        const int ci = chunk * CH + rem % CH, r = tap / 2, s = tap % 2;
+                        const int ci = (chunk * CH + rem % CH) % c0, r = tap / 2, s = tap % 2;
                         return wd[(((size_t)ci * 128 + o) * 4 + kmap[a][r]) * 4 + kmap[b][s]];
                     };
-                    L.finish(h->deconv[a * 2 + b], "pose_net.0.phase" + std::to_string(a * 2 + b), c0, 128, 2, 2, 4 * c0, wt,
-                             &sc, &sh, cb->data.data(), h16);
+                    std::vector<unsigned char> lo_plane;
+                    if (sp) {
+                        lo_plane.assign(4 * cv, 0);
+                        for (int k = 0; k < 4 * cv; ++k) lo_plane[k] = ((k / (CH * 4)) * CH + (k % (CH * 4)) % CH) / c0 == 2;
+                    }
+                    Layer &dl = h->deconv[a * 2 + b];
+                    L.finish(dl, "pose_net.0.phase" + std::to_string(a * 2 + b), cv, 128, 2, 2, 4 * cv, wt,
+                             &sc, &sh, cb->data.data(), h16, sp ? &lo_plane : nullptr);
+                    dl.Kreal = 4 * c0;
+                    if (sp) dl.plane = c0;
                 }
         }
         L.conv(h->pose1, "pose_net.3", "pose_net.3.weight", "pose_net.3.bias", "pose_net.4", 64, 128, 3, 3, 0, h16);

@@ -106,7 +106,7 @@ class HandMvNet(torch.nn.Module):
         return self
 
     def float32x3(self):
-        """fp32-equivalent arithmetic on the fp16 matrix cores (HMV_F32X3; ResNet50-paper and HRNet backbones): every value of the conv
+        """fp32-equivalent arithmetic on the fp16 matrix cores (HMV_F32X3): every value of the conv
         stack travels as a (hi, lo) fp16 pair and every product is hi*hi + lo*hi + hi*lo with fp32 accumulation."""
         if self._dtype != 2:
             self._dtype = 2

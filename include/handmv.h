@@ -38,7 +38,7 @@ enum { HMV_POS2D = 1, HMV_POS_CROP = 2, HMV_POS_SIN = 4 };
 enum { HMV_DECODER_NN = 0, HMV_DECODER_GCN = 1 };
 /* HMV_F16 = BASELINE configs[4]: conv stack in fp16 storage + fp16 MFMA with fp32 accumulation; heat-map
  * logits, soft-argmax, tokens, fusion transformer and decoder stay fp32.  I/O buffers are fp32 either way. */
-/* HMV_F32X3: fp32-equivalent arithmetic on the fp16 matrix cores (ResNet50-paper and HRNet backbones this round).  Every fp32 value of the
+/* HMV_F32X3: fp32-equivalent arithmetic on the fp16 matrix cores (every backbone).  Every fp32 value of the
  * conv stack travels as a (hi, lo) fp16 pair (hi = fp16(v), lo = fp16(v - hi); hi + lo == v to 2^-22) and every product is
  * evaluated as hi*hi + lo*hi + hi*lo with fp32 accumulation -- three 2.5 PFLOP/s fp16 MFMAs instead of one 157 TFLOP/s fp32
  * MFMA.  Same bytes in HBM as fp32.  Heat-map logits, soft-argmax, tokens, fusion and decoder are plain fp32 as always. */

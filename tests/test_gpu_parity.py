@@ -234,7 +234,8 @@ def test_fp16_path_within_its_stated_tolerance(name):
 # maps 1e-6, tokens <= 5.5e-5, joints_cam 2e-6 .. 1.6e-4 -- the same as the fp32 engine).
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["tiny_r50", "cfg1_r50_v4_128", "cfg3s_r50_v8_256", "r50_wocam_nn", "r50_odd_96",
-                                  "hr40_tiny", "hr40_v4_128", "hr64_tiny"])
+                                  "hr40_tiny", "hr40_v4_128", "hr64_tiny", "tiny_r18", "cfg2s_r18_v4_256", "r34_onelevel",
+                                  "r18_frozen_nosin", "r18_single_view", "r18_13views"])
 def test_split_precision_path_meets_the_fp32_bar(name):
     m, cfg, sd, (x, bbox, intr), fx = _model(name)
     m.float32x3()
@@ -249,11 +250,3 @@ def test_split_precision_path_meets_the_fp32_bar(name):
     ref32 = _run(m, x, bbox, intr)
     d = rel_l2(got["feat0"], ref32["feat0"])
     assert 0 < d < 2e-5, d
-
-
-def test_split_precision_is_not_built_for_resnet18():
-    from handmvnet_amd import HandMvNet, _lib
-    cfg, (tp, mp, dp), sd, (x, bbox, intr), fx = load_case("tiny_r18")
-    m = HandMvNet(tp, mp, dp).to("cuda").eval().float32x3()
-    with pytest.raises(_lib.HandMvError, match="ResNet50-paper and HRNet"):
-        m(torch.from_numpy(x).cuda(), torch.from_numpy(bbox).cuda(), {"intrinsic": torch.from_numpy(intr).cuda()})

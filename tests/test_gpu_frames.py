@@ -50,8 +50,9 @@ def test_prepare_frames_matches_oracle_on_camera_sized_frames():
     assert np.allclose(got[1, 2], ((0 - fo.MEAN) / fo.STD)[:, None, None])
 
 
-@pytest.mark.parametrize("name,half", [("tiny_r18", False), ("cfg1_r50_v4_128", False), ("hr40_tiny", False), ("tiny_r50", True)])
-def test_forward_frames_equals_forward_on_prepared_batch(name, half):
+@pytest.mark.parametrize("name,mode", [("tiny_r18", "f32"), ("cfg1_r50_v4_128", "f32"), ("hr40_tiny", "f32"), ("tiny_r50", "f16"),
+                                       ("cfg1_r50_v4_128", "f32x3"), ("hr40_tiny", "f32x3")])
+def test_forward_frames_equals_forward_on_prepared_batch(name, mode):
     from handmvnet_amd import HandMvNet
     cfg, (tp, mp, dp), sd, (x, bbox, intr), fx = load_case(name)
     b, v, size = x.shape[0], x.shape[1], x.shape[-1]
@@ -65,8 +66,11 @@ def test_forward_frames_equals_forward_on_prepared_batch(name, half):
     m = HandMvNet(tp, mp, dp)
     m.load_state_dict(sd, strict=True)
     m.to("cuda").eval()
+    half = mode == "f16"
     if half:
         m.half()
+    elif mode == "f32x3":
+        m.float32x3()
     cam = {"intrinsic": _dev(intr)}
     two_step = m(_dev(fo.prepare_batch(frames, boxes, size)), _dev(boxes.astype(np.float32)), cam)
     fused = m.forward_frames(_dev(frames), _dev(boxes), cam, image_size=size)

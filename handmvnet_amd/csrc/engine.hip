@@ -313,6 +313,7 @@ struct Loader {
                 for (float v : w) mx = std::max(mx, std::fabs(v));
                 int sh = 0;
                 while (sh < 24 && mx > 0.f && mx * 2.f <= 16384.f) { mx *= 2.f; ++sh; }
+                while (sh > -24 && mx > 16384.f) { mx *= 0.5f; --sh; }   // huge folded weights (tiny running_var): scale down instead
                 L.acc_shift = sh;
                 const float f = std::ldexp(1.f, sh);
                 for (float &v : w) v *= f;

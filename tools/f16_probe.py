@@ -1,11 +1,14 @@
-import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tests/golden")
+"""Prints the fp16 path's deviation from the reference fixtures for every case (development tool, GPU box).
+Set HMV_PROBE_MODE=f32x3 to probe the split-precision path instead."""
+import os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for q in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")): sys.path.insert(0, q)
 from helpers import load_case, rel_l2
 from handmvnet_amd import HandMvNet
 from cases import CASES
 for name in CASES:
     cfg, (tp, mp, dp), sd, (x, bbox, intr), fx = load_case(name)
-    m = HandMvNet(tp, mp, dp); m.load_state_dict(sd); m.half(); m.capture_stages(True)
+    m = HandMvNet(tp, mp, dp); m.load_state_dict(sd); (m.float32x3() if os.environ.get("HMV_PROBE_MODE") == "f32x3" else m.half()); m.capture_stages(True)
     dev = torch.device("cuda:0")
     out = m(torch.from_numpy(x).to(dev), torch.from_numpy(bbox).to(dev), {"intrinsic": torch.from_numpy(intr).to(dev)})
     torch.cuda.synchronize()

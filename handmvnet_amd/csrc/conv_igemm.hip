@@ -123,6 +123,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     constexpr int LDC = BN + 4;
     constexpr int AS = stage_blocks(BM, BN, WGM, KB4, RD), SR = WGM * AS * 32;
     static_assert(KB == CH || KB == CH / 2, "k-step");
+    // kernels that also carry the fused split main loop (selected at run time by p.x3_plane)
+    constexpr bool X3CAP = F16 && KB == 64 && MODE != MODE_DENSE && !GENERIC && !PARTN && !RD;
+    const bool x3n = X3CAP && p.x3_plane != 0;
     static_assert(BM % RPS == 0 && BN % RPS == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
     static_assert(TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM, KB4, RD), "epilogue staging");
     static_assert(!RD || (!GENERIC && !PARTN), "row-decomposed epilogue");
@@ -158,6 +161,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     const int lrow = tid / LPR;
     const int kqs = LPR == 8 ? ((tid & 7) ^ ((tid >> 4) & 7)) : ((tid & 3) ^ ((tid >> 4) & 3));
     const T *zero = reinterpret_cast<const T *>(p.zero);
+    // element offset of this lane's 16-byte vector inside a k-step of the A row: 8 consecutive channels per chunk; in the
+    // fused split loop chunks 0-3 are 32 hi channels and chunks 4-7 the same 32 channels of the lo plane
+    const int koff = x3n ? (kqs & 3) * EPC + (kqs >> 2) * p.x3_plane : EPC * kqs;
+    const int kadv = x3n ? KB / 2 : KB;   // channels consumed per k-step
     const T *aptr[AP];
     int astep[AP], hi0[AP], wi0[AP];
     const int HoWo = p.Ho * p.Wo;
@@ -173,10 +180,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
         wi0[i] = wo * p.stride - p.pad_w;
         if (MODE == MODE_1X1) {
             if (ok) { hi0[i] >>= p.up; wi0[i] >>= p.up; }   // nearest-neighbour upsampled input (HRNet fuse)
-            aptr[i] = ok ? base + (hi0[i] * p.W + wi0[i]) * p.lda + EPC * kqs : zero;
-            astep[i] = ok ? KB : 0;
+            aptr[i] = ok ? base + (hi0[i] * p.W + wi0[i]) * p.lda + koff : zero;
+            astep[i] = ok ? kadv : 0;
         } else if (MODE == MODE_TAPS) {
-            aptr[i] = base + (ok ? (hi0[i] * p.W + wi0[i]) * p.lda + EPC * kqs : 0);
+            aptr[i] = base + (ok ? (hi0[i] * p.W + wi0[i]) * p.lda + koff : 0);
             astep[i] = 0;
         } else {
             aptr[i] = base;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
                 if (++cs == p.S) {                                                                          \
                     cs = 0;                                                                                 \
                     cdelta += (p.W - p.S) * p.lda;                                                          \
-                    if (++cr == p.R) { cr = 0; cc += CH; if (F16 && cc == p.cwrap) cc = 0; cdelta = cc; }   \
+                    if (++cr == p.R) { cr = 0; cc += (X3CAP && x3n) ? CH / 2 : CH; if (F16 && cc == p.cwrap) cc = 0; cdelta = cc; } \
                 }                                                                                           \
             }                                                                                               \
         }                                                                                                   \
@@ -266,6 +273,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
             if (!PARTN || tnr > 0) FA[a] = *reinterpret_cast<const f32x4 *>(arow + ((buf) * BM + a * 32) * KB + ch_); \
         _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                      \
             if (!PARTN || b < tnr) FB[b] = *reinterpret_cast<const f32x4 *>(brow + ((buf) * BN + b * 32) * KB + ch_); \
+    }
+#define HMV_FRAG_A(FA, buf, q)                                                                              \
+    {                                                                                                       \
+        const int ch_ = ((2 * (q) + kh) ^ fsw) * EPC;                                                       \
+        _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                      \
+            FA[a] = *reinterpret_cast<const f32x4 *>(arow + ((buf) * BM + a * 32) * KB + ch_);              \
+    }
+#define HMV_FRAG_B(FB, buf, q)                                                                              \
+    {                                                                                                       \
+        const int ch_ = ((2 * (q) + kh) ^ fsw) * EPC;                                                       \
+        _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                      \
+            FB[b] = *reinterpret_cast<const f32x4 *>(brow + ((buf) * BN + b * 32) * KB + ch_);              \
     }
 #define HMV_MFMA(FA, FB)                                                                                    \
     {                                                                                                       \
@@ -295,9 +314,45 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_barrier" ::: "memory");
-    HMV_FRAGS(fa0, fb0, 0, 0);
+    bool done = false;
+    if constexpr (X3CAP) {
+        if (x3n) {
+            // Fused split reduction: an LDS row holds [hi k0-15 | hi k16-31 | lo k0-15 | lo k16-31] (groups 0..3) of 32
+            // channels for A and for W.  Per half h: hi*hi (A[h], W[h]), lo*hi (A[2+h], W[h]), hi*lo (A[h], W[2+h]).
+            f32x4 ah[TM], al[TM], bh[TN], bl[TN], ah2[TM], bh2[TN];
+            HMV_FRAG_A(ah, 0, 0);
+            HMV_FRAG_B(bh, 0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                const int buf = kt & 1;
+                HMV_FRAG_A(al, buf, 2);
+                HMV_MFMA(ah, bh);
+                __builtin_amdgcn_sched_barrier(0);
+                HMV_FRAG_B(bl, buf, 2);
+                HMV_MFMA(al, bh);
+                __builtin_amdgcn_sched_barrier(0);
+                HMV_FRAG_A(ah2, buf, 1);
+                HMV_FRAG_B(bh2, buf, 1);
+                HMV_MFMA(ah, bl);
+                __builtin_amdgcn_sched_barrier(0);
+                HMV_FRAG_A(al, buf, 3);
+                HMV_MFMA(ah2, bh2);
+                __builtin_amdgcn_sched_barrier(0);
+                HMV_FRAG_B(bl, buf, 3);
+                HMV_MFMA(al, bh2);
+                __builtin_amdgcn_sched_barrier(0);
+                // tile kt+1 (the only DMA in flight) must have landed; everyone is done reading `buf`
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (kt + 2 < nk) HMV_DMA(buf);
+                if (kt + 1 < nk) { HMV_FRAG_A(ah, buf ^ 1, 0); HMV_FRAG_B(bh, buf ^ 1, 0); }
+                HMV_MFMA(ah2, bl);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            done = true;
+        }
+    }
+    if (!done) HMV_FRAGS(fa0, fb0, 0, 0);
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; !done && kt < nk; ++kt) {
         const int buf = kt & 1;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {   // fragment sets alternate by the parity of q (NQ is even)
@@ -315,6 +370,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     }
 #undef HMV_DMA
 #undef HMV_FRAGS
+#undef HMV_FRAG_A
+#undef HMV_FRAG_B
 #undef HMV_MFMA
     unsigned long long t1c = 0, t1r = 0;
     if (p.dbg) { t1c = __builtin_amdgcn_s_memtime(); t1r = __builtin_amdgcn_s_memrealtime(); }
@@ -724,6 +781,10 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         tile = TILE_128x128;   // the rarely used epilogue paths exist only for the 4-wave tiles
     const int ch = p.in_f16 ? 64 : 32, epc = p.in_f16 ? 8 : 4;
     const bool dense = p.Cin % ch != 0;
+    // the fused split loop exists in the non-generic fp16 kernels with a 64-element k-step, chunked modes
+    if (p.x3_plane && (!p.in_f16 || generic || p.rd_cout || p.cwrap || p.Cin % 64 != 0 || p.x3_plane % 32 != 0 ||
+                       tile == TILE_128x128_K16))
+        return hipErrorInvalidValue;
     // split operands: fp16 kernels only; the generic epilogue handles them on its vector path only
     if ((p.cwrap || p.res_split || p.out_split || p.acc_shift) &&
         (!p.in_f16 || p.rd_cout || (p.ldc & 3) || (p.res && (p.ldr & 3)) || p.act == ACT_GELU || p.act == ACT_LEAKY))

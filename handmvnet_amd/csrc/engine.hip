@@ -45,6 +45,7 @@ struct Layer {
     int Cin = 0, Cout = 0, R = 1, S = 1, K = 0, Kpad = 0, Cout_pad = 0;
     int Kreal = 0;      // reduction length without channel padding (FLOP accounting)
     int acc_shift = 0;  // HMV_F32X3: the packed weights are W * 2^acc_shift, the epilogue scales the accumulator back
+    bool x3n = false;   // HMV_F32X3: fused split reduction (one tile load per three products; conv_igemm.hip), else the cwrap scheme
     int plane = 0;      // HMV_F32X3 (split operands): physical channels per (hi | lo) plane; Cin is then the virtual 3 * plane
     int rd_cout = 0;    // row-decomposed 3x3 (conv_igemm.hip, RD): the real Cout; Cout / R / S then describe the 3x1 GEMM
     bool f16 = false;   // operands (activations + packed weights) are fp16; bias stays fp32
@@ -341,13 +342,19 @@ struct Loader {
         if (!w || (!bkey.empty() && !cb)) return;
         const int plane = cin_pad ? cin_pad : Cin;            // physical channels (per plane when split)
         const bool sp = split && f16;
-        const int cp = sp ? 3 * plane : plane;                // the channel count the kernel's K order walks
+        // fused split reduction: a k-step = 32 channels as [32 hi | 32 lo] halfs, K order (32-channel chunk, r, s, plane, c % 32)
+        const bool x3n = sp && plane % 32 == 0 && !getenv("HMV_NO_X3N");
+        const int cp = sp ? (x3n ? 2 * plane : 3 * plane) : plane;   // the channel count the kernel's K order walks
         const float *wd = w->data.data();
-        const bool chunked = cp % (f16 ? 64 : 32) == 0 && (!sp || plane % 64 == 0);
+        const bool chunked = cp % (f16 ? 64 : 32) == 0 && (!sp || x3n || plane % 64 == 0);
         auto wt = [=](int o, int k) -> float {
             int c, tap;
             const int CH = f16 ? 64 : 32;
-            if (chunked) {   // K order (chunk, r, s, c % CH), CH = 32 (fp32) / 64 (fp16): conv_igemm.hip
+            if (x3n) {
+                const int step = k / 64, c32 = k % 32;
+                tap = step % (R * S);
+                c = (step / (R * S)) * 32 + c32;
+            } else if (chunked) {   // K order (chunk, r, s, c % CH), CH = 32 (fp32) / 64 (fp16): conv_igemm.hip
                 const int chunk = k / (CH * R * S), rem = k % (CH * R * S);
                 tap = rem / CH;
                 c = chunk * CH + rem % CH;
@@ -355,7 +362,7 @@ struct Loader {
                 c = k % cp;
                 tap = k / cp;
             }
-            if (sp) c %= plane;   // virtual channel -> channel; which plane it is only decides hi / lo (lo_plane below)
+            if (sp && !x3n) c %= plane;   // virtual channel -> channel; which plane it is only decides hi / lo (lo_plane below)
             if (c >= Cin) return 0.f;
             return wd[(((size_t)o * Cin + c) * R + tap / S) * S + tap % S];
         };
@@ -365,6 +372,7 @@ struct Loader {
             lo_plane.assign(Kp, 0);
             for (int k = 0; k < K; ++k) {
                 int c;
+                if (x3n) { lo_plane[k] = (k % 64) >= 32; continue; }
                 if (chunked) { const int chunk = k / (CH * R * S), rem = k % (CH * R * S); c = chunk * CH + rem % CH; }
                 else c = k % cp;
                 lo_plane[k] = c / plane == 2;
@@ -400,7 +408,7 @@ struct Loader {
         finish(L, label, cp, Cout, R, S, R * S * cp, wt, has_bn ? &sc : nullptr, has_bn ? &sh : nullptr,
                cb ? cb->data.data() : nullptr, f16, sp ? &lo_plane : nullptr);
         L.Kreal = R * S * Cin;
-        if (sp) L.plane = plane;
+        if (sp) { L.plane = plane; L.x3n = x3n; }
     }
 
     // nn.Linear weight [out][in] (+ optional bias)
@@ -869,13 +877,14 @@ struct Runner {
         if (L.rd_cout) { p.rd_cout = L.rd_cout; p.pad_w = 0; }   // L.R x L.S is the 3x1 GEMM, the epilogue sums the s groups
         if (L.plane) {   // HMV_F32X3: [hi | lo] rows in, pairs out (unless this layer writes fp32), pairs as residual
             p.lda = 2 * L.plane;
-            p.cwrap = 2 * L.plane;
+            if (L.x3n) p.x3_plane = L.plane;
+            else p.cwrap = 2 * L.plane;
             p.acc_shift = L.acc_shift;
             if (out_f16) { p.out_split = 1; p.ldc = 2 * ldc; }
             if (res) { p.res_split = 1; p.ldr = 2 * ldr; }
         }
         // split layers walk 3x the reduction on fp16 MFMAs: the tile rules see the real reduction length
-        const ConvTile tile = conv_pick_tile(p.M, p.Cout, L.plane ? p.K / 3 : p.K, L.f16, res != nullptr);
+        const ConvTile tile = conv_pick_tile(p.M, p.Cout, L.plane ? p.K / (L.x3n ? 2 : 3) : p.K, L.f16, res != nullptr);
         ProfRec *pr = nullptr;
         if (h->profiling) {
             if (h->prof_used == h->prof.size()) {

@@ -40,6 +40,9 @@ struct ConvParams {
     // and the reduction walks the virtual channel sequence hi, lo, hi against weights packed [W_hi | W_hi | W_lo]
     int cwrap;          // physical channels per pixel (2 * C): a virtual channel offset >= cwrap wraps back to the hi plane (0 = off)
     int res_split;      // residual rows are [hi | lo] pairs (plane stride ldr / 2): value = hi + lo
+    int x3_plane;       // fused split reduction (fp16 kernels, chunked modes, plane % 32 == 0): physical channels per plane.  One
+                        // k-step then carries [A_hi | A_lo] and [W_hi | W_lo] of 32 channels and issues hi*hi, lo*hi, hi*lo from ONE
+                        // tile load (the cwrap scheme loads three); weights are packed per step as 32 hi values, 32 lo values
     int acc_shift;      // split layers: the packed weights are W * 2^acc_shift (keeps W_lo out of the fp16 subnormals);
     float acc_scale;    //   the epilogue multiplies the accumulator by 2^-acc_shift (filled in by launch_conv)
     int out_split;      // write (hi, lo) pairs (plane stride ldc / 2) instead of one fp16 value

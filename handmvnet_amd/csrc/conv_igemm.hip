@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     constexpr int AS = stage_blocks(BM, BN, WGM, KB4, RD), SR = WGM * AS * 32;
     static_assert(KB == CH || KB == CH / 2, "k-step");
     // kernels that also carry the fused split main loop (selected at run time by p.x3_plane)
-    constexpr bool X3CAP = F16 && KB == 64 && MODE != MODE_DENSE && !GENERIC && !PARTN && !RD;
+    constexpr bool X3CAP = F16 && KB == 64 && !GENERIC && !PARTN && !RD;
     const bool x3n = X3CAP && p.x3_plane != 0;
     static_assert(BM % RPS == 0 && BN % RPS == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
     static_assert(TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM, KB4, RD), "epilogue staging");
@@ -217,10 +217,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
         int sr_ = 0, ss_ = 0;                                                                               \
         int sc_ = 0;                                                                                        \
         if (MODE == MODE_DENSE) { /* lane-private (tap, channel offset) of this 16-byte vector */           \
-            const unsigned g_ = (unsigned)(ck / EPC + kqs);                                                 \
+            /* fused split loop: 4 (tap, channel) vectors per k-step, chunks 4-7 fetch the same vectors from the lo plane */ \
+            const unsigned g_ = (X3CAP && x3n) ? (unsigned)(ck / (2 * EPC) + (kqs & 3)) : (unsigned)(ck / EPC + kqs); \
             const unsigned tap_ = p.cpt == 1 ? g_ : __umulhi(g_, p.cpt_magic);   /* g / (Cin / EPC) */      \
             sc_ = (int)(g_ - tap_ * (unsigned)p.cpt) * EPC;                                                 \
             if (F16 && p.cwrap && sc_ >= p.cwrap) sc_ -= p.cwrap;   /* split operands: third plane = hi again */ \
+            if (X3CAP && x3n) sc_ += (kqs >> 2) * p.x3_plane;                                               \
             sr_ = p.S == 1 ? (int)tap_ : (int)__umulhi(tap_, p.s_magic);         /* tap / S */              \
             ss_ = (int)tap_ - sr_ * p.S;                                                                    \
             if (tap_ >= (unsigned)(p.R * p.S)) sr_ = 1 << 29;                                               \
@@ -782,8 +784,8 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     const int ch = p.in_f16 ? 64 : 32, epc = p.in_f16 ? 8 : 4;
     const bool dense = p.Cin % ch != 0;
     // the fused split loop exists in the non-generic fp16 kernels with a 64-element k-step, chunked modes
-    if (p.x3_plane && (!p.in_f16 || generic || p.rd_cout || p.cwrap || p.Cin % 64 != 0 || p.x3_plane % 32 != 0 ||
-                       tile == TILE_128x128_K16))
+    if (p.x3_plane && (!p.in_f16 || generic || p.rd_cout || p.cwrap || p.x3_plane % 8 != 0 || p.Cin != 2 * p.x3_plane ||
+                       (!dense && p.x3_plane % 32 != 0) || tile == TILE_128x128_K16))
         return hipErrorInvalidValue;
     // split operands: fp16 kernels only; the generic epilogue handles them on its vector path only
     if ((p.cwrap || p.res_split || p.out_split || p.acc_shift) &&
@@ -808,7 +810,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     }
     if (dense) {
         if (p.Cin % epc != 0 || p.lda % epc != 0 || generic || p.Kpad > (1 << 16)) return hipErrorInvalidValue;
-        p.cpt = p.Cin / epc;
+        p.cpt = (p.x3_plane ? p.x3_plane : p.Cin) / epc;   // 16-byte vectors per tap (of one plane in the fused split loop)
         p.cpt_magic = p.cpt > 1 ? (unsigned)(0xFFFFFFFFu / (unsigned)p.cpt) + 1u : 0u;
         p.s_magic = p.S > 1 ? (unsigned)(0xFFFFFFFFu / (unsigned)p.S) + 1u : 0u;
         if (p.up && (p.R != 1 || p.S != 1 || p.pad_h || p.pad_w || p.stride != 1)) return hipErrorInvalidValue;

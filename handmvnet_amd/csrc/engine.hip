@@ -343,17 +343,22 @@ struct Loader {
         const int plane = cin_pad ? cin_pad : Cin;            // physical channels (per plane when split)
         const bool sp = split && f16;
         // fused split reduction: a k-step = 32 channels as [32 hi | 32 lo] halfs, K order (32-channel chunk, r, s, plane, c % 32)
-        const bool x3n = sp && plane % 32 == 0 && !getenv("HMV_NO_X3N");
+        const bool x3n = sp && plane % 8 == 0 && !getenv("HMV_NO_X3N");
         const int cp = sp ? (x3n ? 2 * plane : 3 * plane) : plane;   // the channel count the kernel's K order walks
         const float *wd = w->data.data();
-        const bool chunked = cp % (f16 ? 64 : 32) == 0 && (!sp || x3n || plane % 64 == 0);
+        const bool chunked = cp % (f16 ? 64 : 32) == 0 && (!sp || (x3n && plane % 32 == 0) || (!x3n && plane % 64 == 0));
         auto wt = [=](int o, int k) -> float {
             int c, tap;
             const int CH = f16 ? 64 : 32;
-            if (x3n) {
+            if (x3n && chunked) {
                 const int step = k / 64, c32 = k % 32;
                 tap = step % (R * S);
                 c = (step / (R * S)) * 32 + c32;
+            } else if (x3n) {   // dense fused: 4 (tap, 8-channel) vectors per step, K order (r, s, c) over the real channels
+                const int g = (k / 64) * 4 + (k % 32) / 8, cpt = plane / 8;
+                tap = g / cpt;
+                c = (g % cpt) * 8 + k % 8;
+                if (tap >= R * S) return 0.f;
             } else if (chunked) {   // K order (chunk, r, s, c % CH), CH = 32 (fp32) / 64 (fp16): conv_igemm.hip
                 const int chunk = k / (CH * R * S), rem = k % (CH * R * S);
                 tap = rem / CH;
@@ -367,8 +372,10 @@ struct Loader {
             return wd[(((size_t)o * Cin + c) * R + tap / S) * S + tap % S];
         };
         std::vector<unsigned char> lo_plane;
+        // packed reduction length: the dense fused scheme packs 4 (tap, 8-channel) vectors per 64-wide step
+        const int Kpack = (x3n && !chunked) ? (R * S * (plane / 8) + 3) / 4 * 64 : R * S * cp;
         if (sp) {   // packed indices whose virtual channel lies in the third plane
-            const int K = R * S * cp, Kp = round_up(K, 64), CH = 64;
+            const int K = Kpack, Kp = round_up(K, 64), CH = 64;
             lo_plane.assign(Kp, 0);
             for (int k = 0; k < K; ++k) {
                 int c;
@@ -405,7 +412,7 @@ struct Loader {
             L.Kreal = 3 * Cin;   // (3 * Cout) x (3 * Cin) = Cout x 9 * Cin: the FLOP accounting sees the real convolution
             return;
         }
-        finish(L, label, cp, Cout, R, S, R * S * cp, wt, has_bn ? &sc : nullptr, has_bn ? &sh : nullptr,
+        finish(L, label, cp, Cout, R, S, Kpack, wt, has_bn ? &sc : nullptr, has_bn ? &sh : nullptr,
                cb ? cb->data.data() : nullptr, f16, sp ? &lo_plane : nullptr);
         L.Kreal = R * S * Cin;
         if (sp) { L.plane = plane; L.x3n = x3n; }

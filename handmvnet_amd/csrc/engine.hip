@@ -845,6 +845,9 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
     return HMV_OK;
 }
 
+int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                     const float *w_oihw, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad,
+                     const float *residual, int32_t relu, float *out, void *stream);
 }  // extern "C"
 
 // ====================================================================== forward
@@ -1569,3 +1572,59 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
 }
 
 }  // extern "C"
+
+// One conv in any arithmetic mode through the engine's own packing (Loader::conv) and launch path (Runner::conv).
+extern "C" int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                                const float *w_oihw, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
+                                int32_t pad, const float *residual, int32_t relu, float *out, void *stream) {
+    if (dtype == HMV_F32)
+        return hmv_op_conv2d(device, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad, residual, relu, out, stream);
+    if ((dtype != HMV_F16 && dtype != HMV_F32X3) || !in || !w_oihw || !out || Cin % 8 != 0 || Cout % 4 != 0) {
+        g_create_err = "hmv_op_conv2d_ex: dtype must be HMV_F32 / HMV_F16 / HMV_F32X3; the fp16-based modes need Cin % 8 == 0, Cout % 4 == 0";
+        return HMV_ERR_ARG;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hmv_engine eng;
+    eng.cfg.device = device;
+    HostTensor wt;
+    wt.shape = {Cout, Cin, R, S};
+    wt.data.assign(w_oihw, w_oihw + (size_t)Cout * Cin * R * S);
+    eng.host["w"] = wt;
+    if (bias_host) {
+        HostTensor bt;
+        bt.shape = {Cout};
+        bt.data.assign(bias_host, bias_host + Cout);
+        eng.host["b"] = bt;
+    }
+    Loader L{&eng};
+    L.split = dtype == HMV_F32X3;
+    Layer layer;
+    L.conv(layer, "op", "w", bias_host ? "b" : "", "", Cout, Cin, R, S, 0, true);
+    int rc = L.rc;
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    const size_t rows_in = (size_t)N * H * W, rows_out = (size_t)N * Ho * Wo;
+    const int mode = dtype == HMV_F32X3 ? 2 : 1;
+    void *din = nullptr, *dres = nullptr;
+    hipError_t e = hipSuccess;
+    if (rc == HMV_OK) {
+        e = hipMalloc(&din, rows_in * Cin * (mode == 2 ? 4 : 2));
+        if (e == hipSuccess && residual) e = hipMalloc(&dres, rows_out * Cout * (mode == 2 ? 4 : 2));
+        if (e == hipSuccess) e = launch_rows_f32_to_half(in, din, rows_in, Cin, mode, s);
+        if (e == hipSuccess && residual) e = launch_rows_f32_to_half(residual, dres, rows_out, Cout, mode, s);
+        if (e == hipSuccess) {
+            Arena dummy;
+            Runner Rn{&eng, s, false, HMV_OK, dummy};
+            Rn.conv(layer, static_cast<const float *>(din), N, H, W, stride, pad, pad, out, Cout, static_cast<const float *>(dres), Cout,
+                    relu ? ACT_RELU : ACT_NONE, Ho, Wo);
+            rc = Rn.rc;
+            if (rc == HMV_OK) e = hipStreamSynchronize(s);
+        }
+    }
+    if (din) (void)hipFree(din);
+    if (dres) (void)hipFree(dres);
+    for (void *ptr : eng.dev_allocs) (void)hipFree(ptr);
+    if (rc != HMV_OK) { g_create_err = "hmv_op_conv2d_ex: " + eng.err; return rc; }
+    if (e != hipSuccess) { g_create_err = std::string("hmv_op_conv2d_ex: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
+    return HMV_OK;
+}

@@ -84,6 +84,8 @@ hipError_t launch_frames_to_input(const uint8_t *frames, const int *boxes, int N
 hipError_t launch_nchw_to_nhwc_split(const float *x, void *out, int N, int H, int W, hipStream_t s);
 hipError_t launch_maxpool3s2_split(const void *in, void *out, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 hipError_t launch_nhwc_split_to_nchw(const void *in, float *out, int N, int H, int W, int C, hipStream_t s);
+// fp32 rows -> fp16 rows (mode 1) / split [hi | lo] rows (mode 2)
+hipError_t launch_rows_f32_to_half(const float *in, void *out, size_t rows, int C, int mode, hipStream_t s);
 hipError_t launch_maxpool3s2_f16(const void *in, void *out, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 hipError_t launch_nhwc_f16_to_nchw(const void *in, float *out, int N, int H, int W, int C, hipStream_t s);
 // tokens[(n*21+j)][col0 + c] = sum_t w_t * s[(n*21+j)*4+t][c]

@@ -124,6 +124,30 @@ hipError_t launch_nchw_to_nhwc_split(const float *x, void *out, int N, int H, in
     hipLaunchKernelGGL(nchw_to_nhwc_split_kernel, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<f16x8 *>(out), H * W, total);
     return hipGetLastError();
 }
+// fp32 rows [rows][C] -> fp16 rows [rows][C] (mode 1) or split rows [rows][hi C | lo C] (mode 2): op-level tests
+__global__ void rows_f32_to_half_kernel(const float *__restrict__ in, _Float16 *__restrict__ out, int C, int mode, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const size_t r = i / C;
+        const int c = (int)(i - r * C);
+        if (mode == 2) {
+            _Float16 a, b;
+            split_f16(in[i], a, b);
+            out[r * 2 * C + c] = a;
+            out[r * 2 * C + C + c] = b;
+        } else {
+            out[i] = (_Float16)in[i];
+        }
+    }
+}
+hipError_t launch_rows_f32_to_half(const float *in, void *out, size_t rows, int C, int mode, hipStream_t s) {
+    const size_t total = rows * (size_t)C;
+    if (!total) return hipSuccess;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(rows_f32_to_half_kernel, dim3(grid), dim3(256), 0, s, in, reinterpret_cast<_Float16 *>(out), C, mode, total);
+    return hipGetLastError();
+}
 // MaxPool2d(3, 2, 1) on split tensors: the maximum of the reconstructed values, re-split
 __global__ void maxpool3s2_split_kernel(const f16x8 *__restrict__ in, f16x8 *__restrict__ out, int H, int W, int C8, int Ho,
                                         int Wo, size_t total) {

@@ -125,6 +125,13 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
                   const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S,
                   int32_t stride, int32_t pad, const float *residual, int32_t relu, float *out, void *stream);
 
+/* The same op in any arithmetic mode (dtype = HMV_F32 | HMV_F16 | HMV_F32X3): the fp32 input / residual are converted to the
+ * mode's storage format on the device, the layer is packed exactly as hmv_finalize_weights packs it (no BatchNorm), the
+ * output is fp32.  Cin must be a multiple of 8 for the fp16-based modes. */
+int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                     const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
+                     int32_t pad, const float *residual, int32_t relu, float *out, void *stream);
+
 /* Diagnostic micro-benchmark: average milliseconds of `iters` launches of one NHWC conv shape on
  * pseudo-random data.  tile: -1 = the engine's own choice, else 0..7 = 128x32, 128x64, 128x128, 256x128,
  * 128x256, 256x256, 128x128 (k-step 16), 128x256 (k-step 16) (BM x BN).  HMV_BENCH_CLOCK=1 adds in-kernel clock stamps (stderr). */

@@ -108,11 +108,7 @@ CONV_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("shape", CONV_SHAPES)
-def test_conv_kernel_vs_torch(shape):
-    """op-level: one NHWC implicit-GEMM conv vs torch fp64 conv2d on the CPU."""
-    from handmvnet_amd import _lib
-    lib = _lib.load()
+def _conv_case(shape):
     N, H, W, Cin, Cout, k, stride, pad, use_res, relu = shape
     g = torch.Generator().manual_seed(sum(shape[:8]))
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -121,25 +117,55 @@ def test_conv_kernel_vs_torch(shape):
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
     b = torch.randn(Cout, generator=g)
     ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
-    Ho, Wo = ref.shape[2:]
-    res = torch.randn(N, Cout, Ho, Wo, generator=g) if use_res else None
+    res = torch.randn(N, Cout, *ref.shape[2:], generator=g) if use_res else None
     if use_res:
         ref = ref + res.double()
     if relu:
         ref = ref.clamp_min(0)
+    return x, w, b, res, ref
+
+
+def _run_conv(shape, dtype):
+    from handmvnet_amd import _lib
+    lib = _lib.load()
+    N, H, W, Cin, Cout, k, stride, pad, use_res, relu = shape
+    x, w, b, res, ref = _conv_case(shape)
+    Ho, Wo = ref.shape[2:]
     dev = torch.device("cuda:0")
     xin = x.permute(0, 2, 3, 1).contiguous().to(dev)
     out = torch.full((N, Ho, Wo, Cout), float("nan"), device=dev)
     rdev = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
     wc, bc = w.contiguous().numpy(), b.contiguous().numpy()
-    rc = lib.hmv_op_conv2d(0, xin.data_ptr(), N, H, W, Cin, wc.ctypes.data_as(ctypes.c_void_p),
-                           bc.ctypes.data_as(ctypes.c_void_p), Cout, k, k, stride, pad,
-                           rdev.data_ptr() if use_res else None, int(relu), out.data_ptr(), None)
+    rc = lib.hmv_op_conv2d_ex(0, dtype, xin.data_ptr(), N, H, W, Cin, wc.ctypes.data_as(ctypes.c_void_p),
+                              bc.ctypes.data_as(ctypes.c_void_p), Cout, k, k, stride, pad,
+                              rdev.data_ptr() if use_res else None, int(relu), out.data_ptr(), None)
     assert rc == 0, lib.hmv_last_error(None)
     got = out.cpu().permute(0, 3, 1, 2).double()
     assert torch.isfinite(got).all()
-    err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
-    assert err < 2e-6, err
+    return (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv_kernel_vs_torch(shape):
+    """op-level: one NHWC implicit-GEMM conv (native fp32 MFMA) vs torch fp64 conv2d on the CPU."""
+    assert _run_conv(shape, 0) < 2e-6
+
+
+HALF_SHAPES = [sh for sh in CONV_SHAPES if sh[3] % 8 == 0 and sh[4] % 4 == 0]
+
+
+@pytest.mark.parametrize("shape", HALF_SHAPES)
+def test_conv_kernel_split_precision_vs_torch(shape):
+    """The same op with (hi, lo) fp16 pairs and three fp16 MFMAs per product (HMV_F32X3): held to fp32-grade error.
+    (The inputs and the residual are themselves rounded to hi + lo, 2^-22 relative; the fp32 kernel's bound is 2e-6.)"""
+    assert _run_conv(shape, 2) < 3e-6
+
+
+@pytest.mark.parametrize("shape", HALF_SHAPES)
+def test_conv_kernel_fp16_vs_torch(shape):
+    """... and with plain fp16 operands, fp32 accumulation: fp16-grade error."""
+    err = _run_conv(shape, 1)
+    assert 1e-6 < err < 2e-3, err
 
 
 def test_full_size_properties():

@@ -118,17 +118,17 @@ class Oracle:
         intrinsic = np.ascontiguousarray(intrinsic, dtype=np.float32)
         B, V, _, H, W = x.shape
         assert V == cfg.num_views
-        hs = H // 8
+        hs, ws = H // 8, W // 8
         d = cfg.feat_dim
         out = {
             "joints_crop_img": np.zeros((B, V, 21, 2), np.float32),
             "joints_cam": np.zeros((B, 21, 3), np.float32),
-            "heatmap": np.zeros((B, V, 21, hs, hs), np.float32),
+            "heatmap": np.zeros((B, V, 21, hs, ws), np.float32),
         }
         st = {}
         if stages:
-            fh = H // 4 if cfg.is_hrnet else (hs if cfg.is_paper else H // 16)
-            st = {"feat0": np.zeros((B * V, cfg.backbone_channels[0], fh, fh), np.float32),
+            fdiv = 4 if cfg.is_hrnet else (8 if cfg.is_paper else 16)
+            st = {"feat0": np.zeros((B * V, cfg.backbone_channels[0], H // fdiv, W // fdiv), np.float32),
                   "coords_hm": np.zeros((B * V, 21, 2), np.float32),
                   "tokens": np.zeros((B, V * 21, d), np.float32),
                   "fused": np.zeros((B, 21, d), np.float32)}

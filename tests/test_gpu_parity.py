@@ -83,6 +83,29 @@ def test_forward_matches_oracle(name):
     assert np.abs(got["joints_crop_img"] - ref["joints_crop_img"]).max() < 0.05 * cfg.image_size / cfg.heatmap_size
 
 
+@pytest.mark.parametrize("name,mode", [("tiny_r18", "f32"), ("tiny_r50", "f32"), ("hr40_tiny", "f32"), ("tiny_r50", "f32x3"),
+                                       ("hr40_tiny", "f32x3")])
+def test_non_square_frames_match_oracle(name, mode):
+    """H != W (the reference takes any frame size; every fixture is square): 64 x 96 and 96 x 64 frames against the oracle."""
+    from oracle.oracle import Oracle
+    from handmvnet_amd.synth import normalish
+    m, cfg, sd, (x, bbox, intr), fx = _model(name)
+    if mode == "f32x3":
+        m.float32x3()
+    orc = Oracle(cfg, sd, "f64")
+    for hh, ww in ((64, 96), (96, 64)):
+        b, v = x.shape[:2]
+        xs = normalish("input.nonsquare", 23 + hh, b * v * 3 * hh * ww).astype(np.float32).reshape(b, v, 3, hh, ww)
+        got = _run(m, xs, bbox, intr)
+        ref = orc.forward(xs, bbox, intr, stages=True)
+        assert got["heatmap"].shape == ref["heatmap"].shape == (b, v, 21, hh // 8, ww // 8)
+        rep = {k: rel_l2(got[k], ref[k]) for k in ("joints_cam", "heatmap", "feat0", "tokens", "fused")}
+        rep["coords"] = float(np.abs(got["coords_hm"] - ref["coords_hm"]).max())
+        print(name, mode, (hh, ww), rep)
+        assert rep["joints_cam"] <= TOL_CAM and rep["coords"] < 0.05, rep
+        assert max(rep["heatmap"], rep["feat0"], rep["tokens"], rep["fused"]) <= TOL_STAGE, rep
+
+
 CONV_SHAPES = [
     # N, H, W, Cin, Cout, k, stride, pad, residual, relu
     (2, 16, 16, 64, 64, 1, 1, 0, False, True),

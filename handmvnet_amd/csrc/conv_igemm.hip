@@ -35,6 +35,14 @@
 //     activation tile is pulled from HBM once per XCD and re-read from that XCD's L2.
 //   * epilogue fused: folded-BN shift / bias, residual add, ReLU / GELU(erf) / LeakyReLU, staged
 //     through LDS so that global traffic is 16-byte vectors on full output rows.
+//
+// Variants of the same template (DESIGN.md section 4 has the measurements):
+//   * T = _Float16: v_mfma_f32_32x32x16_f16, fp32 accumulation, byte-identical LDS image / DMA pattern (k-step 64).
+//   * MODE_DENSE: K = plain (r, s, c) over the REAL channels for Cin % 32 != 0 (stem, HRNet's 40 / 80-channel tensors).
+//   * PARTN ("skipN"): all-padding 32-column blocks of the last N tile are skipped (Cout = 80 / 160 / 320).
+//   * RD ("rowsum"): row-decomposed 3x3 conv for narrow outputs (3x1 GEMM with (s, cout) columns + row-sum epilogue).
+//   * split operands (HMV_F32X3, fp16 kernels): fp32 values as (hi, lo) fp16 pairs, hi*hi + lo*hi + hi*lo; the fused loop
+//     issues the three products from one tile load (x3_plane), the cwrap loop walks hi, lo, hi as a 3x longer reduction.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>

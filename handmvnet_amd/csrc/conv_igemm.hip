@@ -62,12 +62,19 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #endif
 
 // 256 bytes of zeros: out-of-range taps / rows DMA from here.
-static float *g_zero_page = nullptr;
-static hipError_t ensure_zero_page() {
-    if (g_zero_page) return hipSuccess;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&g_zero_page), 256);
-    if (e == hipSuccess) e = hipMemset(g_zero_page, 0, 256);
-    return e;
+static float *g_zero_page[64] = {};   // one per device ordinal
+static hipError_t ensure_zero_page(float **page) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!g_zero_page[dev]) {
+        e = hipMalloc(reinterpret_cast<void **>(&g_zero_page[dev]), 256);
+        if (e == hipSuccess) e = hipMemset(g_zero_page[dev], 0, 256);
+        if (e != hipSuccess) { g_zero_page[dev] = nullptr; return e; }
+    }
+    *page = g_zero_page[dev];
+    return hipSuccess;
 }
 
 // A-operand addressing modes
@@ -747,14 +754,16 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool /*has_res*/) {
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false>
 static hipError_t launch_one(ConvParams p, hipStream_t s) {
-    static bool configured = false;
+    static bool configured[64] = {};   // per device ordinal
     const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4, RD) * sizeof(float);
     auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD>;
-    if (!configured) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!configured[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured[dev] = true;
     }
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.Cout + BN - 1) / BN;
@@ -776,10 +785,11 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     if (name) *name = "conv_igemm<none>";
     if (p.M <= 0) return hipSuccess;
     {
-        hipError_t e = ensure_zero_page();
+        float *page = nullptr;
+        hipError_t e = ensure_zero_page(&page);
         if (e != hipSuccess) return e;
+        p.zero = page;
     }
-    p.zero = g_zero_page;
     if (!p.lda) p.lda = p.Cin;
     if (!p.ldw) p.ldw = p.Kpad;
     p.acc_scale = ldexpf(1.f, -p.acc_shift);

@@ -31,6 +31,10 @@ def family(name: str) -> str:
         k16 = ",k16" if (t == "f32" and m.group(5) == "16") else ""
         skip = ",skipN" if m.group(6) == "true" else ""
         return f"conv_igemm_{t}<{m.group(2)}x{m.group(3)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense"}[m.group(4)] + skip + ">"
+    # rocprofv3 leaves the _Float16 instantiations mangled (DF16_): conv_igemm<_Float16, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD>
+    m = re.match(r"_ZN3hmv10conv_igemmIDF16_Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)ELb[01]ELi(\d+)E", name)
+    if m:
+        return f"conv_igemm_f16<{m.group(1)}x{m.group(2)}," + {"0": "taps", "1": "1x1", "2": "dense"}[m.group(3)] + ">"
     return re.sub(r"\(.*", "", name).replace("void ", "").replace("hmv::", "")
 
 
@@ -78,9 +82,10 @@ def main():
     out = {"tag": tag, "sq": dict(sorted(sq.items(), key=lambda kv: -kv[1]["total_ms"])), "traffic": traffic,
            "corrections": "FETCH_SIZE x2 (gfx950 wide loads), KiB -> bytes; WRITE_SIZE exact"}
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
-    json.dump({"source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)",
-               "kernels": {f: t["hbm_bytes_per_launch"] for f, t in traffic.items()}},
-              open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    if "--no-traffic-file" not in sys.argv:   # pmc_traffic.json belongs to the default (fp32) bench run
+        json.dump({"source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)",
+                   "kernels": {f: t["hbm_bytes_per_launch"] for f, t in traffic.items()}},
+                  open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     for f, v in list(out["sq"].items())[:6]:
         print(f, v, {k: round(x / 1e6, 1) for k, x in traffic.get(f, {}).items() if k.endswith("launch")})
 

@@ -60,6 +60,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #ifndef HMV_UB
 #define HMV_UB 4   // output rows (16-byte vectors) in flight per thread in the epilogue
 #endif
+#ifndef HMV_UB_F16
+#define HMV_UB_F16 4   // the same for the fp16 kernels' drain
+#endif
 
 // 256 bytes of zeros: out-of-range taps / rows DMA from here.
 static float *g_zero_page[64] = {};   // one per device ordinal
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
             // residual-bearing fp16 layers at ~3 TB/s)
             auto drain = [&](auto wtag) {
                 constexpr int W = decltype(wtag)::value, W4 = W / 4;
-                constexpr int TPR = BN / W, RPP = NT / TPR, NPASS = SR / RPP, UB = NPASS < HMV_UB ? NPASS : HMV_UB;
+                constexpr int TPR = BN / W, RPP = NT / TPR, NPASS = SR / RPP, UB = NPASS < HMV_UB_F16 ? NPASS : HMV_UB_F16;
                 static_assert(SR % RPP == 0 && NPASS % UB == 0, "staging pass shape");
                 const int cw = tid % TPR, r0 = tid / TPR;
                 const int col = n0 + W * cw;

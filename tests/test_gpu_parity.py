@@ -191,6 +191,34 @@ def test_conv_kernel_fp16_vs_torch(shape):
     assert 1e-6 < err < 2e-3, err
 
 
+def _random_conv_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    shapes = []
+    while len(shapes) < n:
+        cin = int(rng.choice([4, 8, 12, 16, 24, 32, 40, 64, 80, 96, 160, 256]))
+        cout = int(rng.choice([4, 8, 20, 32, 40, 64, 80, 96, 128, 160, 200, 256, 320]))
+        k = int(rng.choice([1, 1, 3, 3, 5]))
+        stride = int(rng.choice([1, 1, 2]))
+        pad = int(rng.choice([0, k // 2]))
+        nimg, hh, ww = int(rng.integers(1, 4)), int(rng.integers(k, 34)), int(rng.integers(k, 34))
+        shapes.append((nimg, hh, ww, cin, cout, k, stride, pad, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+    return shapes
+
+
+@pytest.mark.parametrize("dtype,tol", [(0, 4e-6), (2, 5e-6), (1, 3e-3)])   # reductions up to K = 6400: sqrt(K) growth
+def test_conv_kernel_random_shapes(dtype, tol):
+    """48 seeded random shapes per arithmetic mode (ragged M / N / K tails, dense and chunked K orders, every tile rule the
+    small sizes reach) against torch fp64."""
+    worst = 0.0
+    for shape in _random_conv_shapes(48, seed=1234):
+        if dtype != 0 and shape[3] % 8 != 0:
+            continue
+        err = _run_conv(shape, dtype)
+        assert err < tol, (shape, dtype, err)
+        worst = max(worst, err)
+    print("worst", dtype, worst)
+
+
 def test_full_size_properties():
     """BASELINE.json configs[2] size (B=32, V=8, 256x256, r50-paper): determinism and
     batch-independence (sample i alone == sample i inside the batch, bit for bit)."""

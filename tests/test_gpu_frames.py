@@ -101,6 +101,27 @@ def test_prepare_frames_full_size_properties():
     assert bool(((a >= lo - 1e-5) & (a <= hi + 1e-5)).all())
 
 
+def test_prepare_frames_random_windows_match_oracle():
+    """40 seeded random (frame, window, output size) combinations: 1-pixel windows, heavy up- and down-sampling, windows
+    straddling every edge or missing the frame entirely, non-square windows."""
+    from handmvnet_amd.frames import prepare_frames
+    rng = np.random.default_rng(99)
+    worst = 0.0
+    for _ in range(40):
+        hf, wf = int(rng.integers(8, 70)), int(rng.integers(8, 90))
+        size = int(rng.choice([8, 16, 24, 32, 48]))
+        frames = rng.integers(0, 256, (3, hf, wf, 3), dtype=np.uint8)
+        x1, y1 = rng.integers(-30, wf + 10, 3), rng.integers(-30, hf + 10, 3)
+        bw, bh = rng.integers(1, 120, 3), rng.integers(1, 120, 3)
+        boxes = np.stack([x1, y1, x1 + bw, y1 + bh], axis=-1).astype(np.int32)
+        got = prepare_frames(_dev(frames), _dev(boxes), size).cpu().numpy()
+        want = fo.prepare_batch(frames, boxes, size)
+        err = float(np.abs(got - want).max())
+        assert err < 1e-5, (hf, wf, size, boxes.tolist(), err)
+        worst = max(worst, err)
+    print("worst", worst)
+
+
 def test_garbage_boxes_are_bounded_and_black():
     """int32 extremes and absurd windows: no overflow, no unbounded loop; they come out as the black view."""
     from handmvnet_amd.frames import prepare_frames

@@ -813,7 +813,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         (!p.in_f16 || p.rd_cout || (p.ldc & 3) || (p.res && (p.ldr & 3)) || p.act == ACT_GELU || p.act == ACT_LEAKY))
         return hipErrorInvalidValue;
     if (p.rd_cout) {   // row-decomposed 3x3 (see conv_igemm): the caller passes the 3x1 GEMM (R = 3, S = 1, Cout = 3 * rd_cout)
-        if (generic || p.R != 3 || p.S != 1 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 0 || p.Cout != 3 * p.rd_cout || p.Cout > 128 ||
+        if (generic || p.R != 3 || p.S != 1 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 0 || p.Cout != 3 * p.rd_cout || p.Cout > 256 ||
             (p.rd_cout & 3) || (p.ldc & 3) || (p.res && (p.ldr & 3)) || 128 % p.Wo != 0 || p.Ho != p.H || p.Wo != p.W)
             return hipErrorInvalidValue;
         if (dense) {
@@ -822,12 +822,16 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
             p.cpt_magic = p.cpt > 1 ? (unsigned)(0xFFFFFFFFu / (unsigned)p.cpt) + 1u : 0u;
             p.s_magic = 0u;
         }
-        if (name) *name = tile_name(p.in_f16 ? "f16" : "f32", TILE_128x128, dense ? 2 : 0, false, true);
-        if (p.in_f16)
-            return dense ? launch_one<_Float16, 128, 128, 2, 2, MODE_DENSE, false, 64, false, true>(p, s)
-                         : launch_one<_Float16, 128, 128, 2, 2, MODE_TAPS, false, 64, false, true>(p, s);
-        return dense ? launch_one<float, 128, 128, 2, 2, MODE_DENSE, false, 32, false, true>(p, s)
-                     : launch_one<float, 128, 128, 2, 2, MODE_TAPS, false, 32, false, true>(p, s);
+        const bool wide = p.Cout > 128;   // 3 * 80 = 240 columns: a 128x256 tile (8 waves)
+        if (name) *name = tile_name(p.in_f16 ? "f16" : "f32", wide ? TILE_128x256 : TILE_128x128, dense ? 2 : 0, false, true);
+#define HMV_RD(T_, KB_)                                                                                                  \
+        if (wide) return dense ? launch_one<T_, 128, 256, 2, 4, MODE_DENSE, false, KB_, false, true>(p, s)                  \
+                               : launch_one<T_, 128, 256, 2, 4, MODE_TAPS, false, KB_, false, true>(p, s);                  \
+        return dense ? launch_one<T_, 128, 128, 2, 2, MODE_DENSE, false, KB_, false, true>(p, s)                            \
+                     : launch_one<T_, 128, 128, 2, 2, MODE_TAPS, false, KB_, false, true>(p, s);
+        if (p.in_f16) { HMV_RD(_Float16, 64) }
+        HMV_RD(float, 32)
+#undef HMV_RD
     }
     if (dense) {
         if (p.Cin % epc != 0 || p.lda % epc != 0 || generic || p.Kpad > (1 << 16)) return hipErrorInvalidValue;

@@ -514,7 +514,12 @@ int hmv_finalize_weights(hmv_handle h) {
         for (int i = 0; i < 4; ++i) hr.ch[i] = kHrChannels[c.backbone - HMV_HRNET_W40][i];
         // the highest-resolution branch (H/4 x W/4) of w40 has 40 channels: its stride-1 3x3 convs run row-decomposed
         // when a 128-row tile covers whole image rows (conv_igemm.hip, RD)
-        const bool rd0 = 3 * hr.ch[0] <= 128 && hr.ch[0] % 4 == 0 && 128 % (c.width / 4) == 0 && !L.split && !getenv("HMV_NO_ROWSUM");
+        // (only where it removes padding: channel counts that are not multiples of 32, i.e. w40's 40- and 80-wide branches)
+        bool rdb[4] = {false, false, false, false};
+        for (int b = 0; b < 2; ++b)
+            rdb[b] = 3 * hr.ch[b] <= 256 && hr.ch[b] % 32 != 0 && hr.ch[b] % 4 == 0 && 128 % (c.width / (4 << b)) == 0 && !L.split &&
+                     !getenv("HMV_NO_ROWSUM");
+        const bool rd0 = rdb[0];
         L.conv(hr.conv1, "stem.conv1", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 3, 3, /*cin_pad=*/h16 ? 8 : 4, h16);
         L.conv(hr.conv2, "stem.conv2", "backbone.conv2.weight", "", "backbone.bn2", 64, 64, 3, 3, 0, h16);
         int inpl_ = 64;
@@ -567,8 +572,8 @@ int hmv_finalize_weights(hmv_handle h) {
                     for (int blk = 0; blk < 4; ++blk) {
                         const std::string bp = mp + ".branches." + std::to_string(b) + "." + std::to_string(blk);
                         const std::string bl = ml + ".b" + std::to_string(b) + "." + std::to_string(blk);
-                        L.conv(M.br[b][blk][0], bl + ".conv1", bp + ".conv1.weight", "", bp + ".bn1", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]), h16, b == 0 && rd0);
-                        L.conv(M.br[b][blk][1], bl + ".conv2", bp + ".conv2.weight", "", bp + ".bn2", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]), h16, b == 0 && rd0);
+                        L.conv(M.br[b][blk][0], bl + ".conv1", bp + ".conv1.weight", "", bp + ".bn1", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]), h16, rdb[b]);
+                        L.conv(M.br[b][blk][1], bl + ".conv2", bp + ".conv2.weight", "", bp + ".bn2", hr.ch[b], hr.ch[b], 3, 3, cpad(hr.ch[b]), h16, rdb[b]);
                     }
                 for (int i = 0; i < nbr; ++i)
                     for (int j = 0; j < nbr; ++j) {

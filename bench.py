@@ -36,6 +36,7 @@ from handmvnet_amd.synth import synth_inputs, synth_state_dict  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_HBM_GBS = 8000.0          # same guide, "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured with a float4 copy)
 
 WORKLOADS = {
     # name: (backbone_type, channels, V, B per GPU, size)
@@ -89,9 +90,69 @@ def cpu_baseline(cfg, sd, size, model, dev, min_seconds=10.0):
     got = out["joints_cam"].cpu().numpy()
     rel = float(np.linalg.norm(got - ref["joints_cam"]) / np.linalg.norm(ref["joints_cam"]))
     frames = n * cfg.num_views
-    return {"value": round(frames / el, 3), "unit": "frames/s", "cores": orc.num_threads, "kind": "port",
-            "sample": f"{n} forwards of B=1 x V={cfg.num_views} x {size}x{size} ({frames} frames, {el:.1f} s) "
-                      f"through oracle/hmv_oracle.c (fp32, OpenMP)"}, rel
+    cb = {"value": round(frames / el, 3), "unit": "frames/s", "cores": orc.num_threads, "kind": "port",
+          "sample": f"{n} forwards of B=1 x V={cfg.num_views} x {size}x{size} ({frames} frames, {el:.1f} s) "
+                    f"through oracle/hmv_oracle.c (fp32, OpenMP)"}
+    try:   # the REAL reference (PyTorch CPU) timed in the build container on the same shape: it cannot travel to this box
+        with open(os.path.join(ROOT, "profiles", "ref_pytorch_cpu.json")) as f:
+            ref_cpu = json.load(f)
+        key = f"{cfg.backbone_type}_B1_V{cfg.num_views}_{size}"
+        if key in ref_cpu.get("shapes", {}):
+            cb["reference_pytorch_cpu"] = dict(ref_cpu["shapes"][key], where=ref_cpu["where"], note=ref_cpu["note"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return cb, rel
+
+
+def launch_command(n_ranks: int, argv, port: int):
+    """The torchrun command line the parent uses to start `n_ranks` ranks of this script (one process per GPU)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_ranks: int, argv) -> int:
+    """`python bench.py --gpus N` with no torchrun around it: start the N ranks as CHILD processes (the parent has made no
+    GPU call -- importing torch does not initialise HIP -- and never execs), relay rank 0's JSON line, return the
+    children's status."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(launch_command(n_ranks, argv, port), stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:          # rank 0 prints the one JSON line; anything else the children say goes to stderr
+        line = line.rstrip("\n")
+        is_json = False
+        if line.startswith("{"):
+            try:
+                json.loads(line)
+                is_json = True
+            except ValueError:
+                pass
+        print(line, file=sys.stdout if is_json else sys.stderr, flush=True)
+    return proc.wait()
+
+
+def launch_check(world: int, rank: int):
+    """--launch-check: the multi-rank control flow without the GPU work (CPU test of the launcher): rendezvous over gloo,
+    one all-reduce, barrier, rank 0 prints the JSON line."""
+    if os.environ.get("HMV_BENCH_FAIL_RANK") == str(rank):   # test hook: a dying rank must fail the whole launch
+        raise SystemExit(3)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        dist.barrier()
+        total = float(t.item())
+        dist.destroy_process_group()
+    else:
+        total = 1.0
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": total}), flush=True)
 
 
 def main():
@@ -115,14 +176,21 @@ def main():
                          "separate instrumented pass afterwards")
     ap.add_argument("--graphs", action="store_true", help="opt into hipGraph replay for the un-instrumented steps")
     ap.add_argument("--per-layer", default="", help="write per-layer launch timings (JSON) to this file")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only exercise the rank launch / rendezvous / relay path (gloo, no GPU work): CPU test of --gpus N")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: this process becomes the launcher.  Nothing here has touched the GPU yet.
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    if args.launch_check:
+        launch_check(world, rank)
+        return
     # rehearsal switches for a one-GPU box: HMV_BENCH_SAME_DEVICE=1 maps every rank to cuda:0 and
     # HMV_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU); never set by the driver
     same_dev = os.environ.get("HMV_BENCH_SAME_DEVICE") == "1"
@@ -209,39 +277,56 @@ def main():
     if rank == 0 and args.per_layer:
         lay = {}
         for r in recs:
-            e = lay.setdefault(r["layer"], {"kernel": r["kernel"], "ms": 0.0, "flops": r["flops"], "n": 0})
+            e = lay.setdefault(r["layer"], {"kernel": r["kernel"], "ms": 0.0, "flops": r["flops"], "bytes": r["bytes"], "n": 0})
             e["ms"] += r["ms"]; e["n"] += 1
         rows = [{"layer": k, "kernel": v["kernel"], "avg_ms": v["ms"] / v["n"], "gflop": v["flops"] / 1e9,
-                 "tflops": v["flops"] / (v["ms"] / v["n"] * 1e-3) / 1e12} for k, v in lay.items()]
+                 "tflops": v["flops"] / (v["ms"] / v["n"] * 1e-3) / 1e12, "mbytes": v["bytes"] / 1e6,
+                 "gbs": v["bytes"] / (v["ms"] / v["n"] * 1e-3) / 1e9} for k, v in lay.items()]
         with open(args.per_layer, "w") as f:
             json.dump(rows, f, indent=1)
     if rank == 0:
-        # ---- roofline of the dominant kernel from the live per-launch event timings
+        # ---- roofline of the dominant kernel family from the live per-launch event timings.  Each launch carries its
+        # algorithmic FLOPs (2*M*N*K over the real channels) and algorithmic HBM bytes (input pixels, weights, residual and
+        # output rows moved once in the mode's storage type); the family's bound is whichever floor is higher:
+        # bytes / 8 TB/s (HBM) or FLOPs / the MFMA peak of the dtype it multiplies in (min(MFMA, HBM)).
         fam = {}
         for r in recs:
-            f = fam.setdefault(r["kernel"], {"ms": 0.0, "flops": 0.0, "n": 0})
-            f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["n"] += 1
+            f = fam.setdefault(r["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+            f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["bytes"] += r["bytes"]; f["n"] += 1
+        for k, v in fam.items():
+            v["peak_tflops"] = PEAK_F16_MFMA_TFLOPS if "f16" in k else PEAK_F32_MFMA_TFLOPS
+            mult = 3.0 if (args.dtype == "f32x3" and "f16" in k) else 1.0      # executed MFMA work per algorithmic FLOP
+            v["t_mfma"] = mult * v["flops"] / (v["peak_tflops"] * 1e12)
+            v["t_hbm"] = v["bytes"] / (PEAK_HBM_GBS * 1e9)
+            v["bound"] = "hbm" if v["t_hbm"] > v["t_mfma"] else "mfma"
+            v["frac"] = max(v["t_hbm"], v["t_mfma"]) / (v["ms"] * 1e-3)
         dom = max(fam, key=lambda k: fam[k]["ms"])
         d = fam[dom]
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        peak = PEAK_F16_MFMA_TFLOPS if "f16" in dom else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_src = None, None
         try:   # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pt = json.load(f)
-            if dom in pt["kernels"] and args.workload == "cfg3" and B == 32 and args.dtype == "f32":
+            pt = pt.get(args.dtype, pt if "kernels" in pt else {})
+            if dom in pt.get("kernels", {}) and args.workload == "cfg3" and B == 32 and pt.get("dtype", "f32") == args.dtype:
                 traffic, traffic_src = round(pt["kernels"][dom]), pt["source"]
         except (OSError, ValueError, KeyError):
             pass
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+        if d["bound"] == "hbm":
+            achieved, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+        else:
+            achieved, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, d["peak_tflops"], "TFLOP/s"
+        roofline = {"bound": d["bound"], "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
+                    "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "launches_per_step": d["n"] // max(n_instr, 1), "avg_launch_ms": round(d["ms"] / d["n"], 4),
-                    "flops_per_launch": d["flops"] / d["n"]}
-        if args.dtype == "f32x3":   # three fp16 MFMAs per algorithmic multiply-add
-            roofline["executed_tflops"] = round(3 * achieved, 2)
-            roofline["executed_frac"] = round(3 * achieved / peak, 4)
-            roofline["note"] = "achieved counts algorithmic fp32 FLOPs; the fp16 matrix cores execute 3x that (hi*hi + lo*hi + hi*lo)"
+                    "flops_per_launch": d["flops"] / d["n"], "bytes_per_launch": d["bytes"] / d["n"],
+                    "floor_ms_per_launch": {"hbm@8TB/s": round(d["t_hbm"] / d["n"] * 1e3, 4),
+                                            "mfma": round(d["t_mfma"] / d["n"] * 1e3, 4)}}
+        if args.dtype == "f32x3" and "f16" in dom:   # three fp16 MFMAs per algorithmic multiply-add
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            roofline["executed_tflops"] = round(3 * tf, 2)
+            roofline["executed_frac"] = round(3 * tf / d["peak_tflops"], 4)
+            roofline["note"] = "algorithmic fp32 FLOPs; the fp16 matrix cores execute 3x that (hi*hi + lo*hi + hi*lo)"
         ms_step = elapsed / args.steps * 1e3
         # dense algorithmic count for the ResNet workloads; for HRNet the executed FLOPs of the
         # conv/GEMM launches of one step (the engine's own 2*M*N*K accounting)
@@ -263,7 +348,8 @@ def main():
             "forward": {"algorithmic_gflop": round(total_flops / 1e9, 1),
                         "tflops": round(total_flops / (ms_step * 1e-3) / 1e12, 2),
                         "frac_of_f32_mfma_peak": round(total_flops / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
-            "kernels": {k: {"ms_per_step": round(v["ms"] / n_instr, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+            "kernels": {k: {"ms_per_step": round(v["ms"] / n_instr, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                            "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "bound": v["bound"], "frac": round(v["frac"], 4)}
                         for k, v in fam.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

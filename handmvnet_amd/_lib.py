@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("HMV_LIB") or os.path.join(_HERE, "libhandmv.so")   # 
 SYMBOLS = ["hmv_create", "hmv_set_tensor", "hmv_finalize_weights", "hmv_workspace_bytes", "hmv_reserve", "hmv_forward",
            "hmv_last_error", "hmv_destroy", "hmv_set_capture", "hmv_read_stage", "hmv_set_profiling", "hmv_profile_count",
            "hmv_profile_get", "hmv_op_conv2d", "hmv_op_conv2d_ex", "hmv_bench_conv", "hmv_pose_metrics", "hmv_forward_frames",
-           "hmv_op_prepare_frames", "hmv_set_graphs", "hmv_graph_stats", "hmv_version"]
+           "hmv_op_prepare_frames", "hmv_set_graphs", "hmv_graph_stats", "hmv_version", "hmv_profile_get_bytes"]
 
 HMV_OK = 0
 
@@ -59,6 +59,8 @@ def load() -> ctypes.CDLL:
     lib.hmv_profile_count.argtypes = [vp]
     lib.hmv_profile_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
                                     ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
+    lib.hmv_profile_get_bytes.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
+    lib.hmv_profile_get_bytes.restype = ctypes.c_int
     lib.hmv_op_conv2d.argtypes = [ci, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, ci, fp, ci, fp, vp]
     lib.hmv_op_conv2d_ex.argtypes = [ci, ci, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, ci, fp, ci, fp, vp]
     lib.hmv_op_conv2d_ex.restype = ctypes.c_int

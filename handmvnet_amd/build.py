@@ -52,5 +52,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, defines, verbose: bool = False) -> str:
+    """A/B builds for one-box comparisons: compiles every source with extra -D flags into build/libhandmv_<name>.so
+    (load it with HMV_LIB=build/libhandmv_<name>.so).  Development tool; the product is build()."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out_dir = os.path.join(os.path.dirname(HERE), "build", name)
+    os.makedirs(out_dir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        op = os.path.join(out_dir, src.replace(".hip", ".o"))
+        objs.append(op)
+        cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, src), "-o", op]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    lib = os.path.join(os.path.dirname(HERE), "build", f"libhandmv_{name}.so")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:   # python -m handmvnet_amd.build --variant stage HMV_TOUT=0
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

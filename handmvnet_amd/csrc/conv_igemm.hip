@@ -63,6 +63,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #ifndef HMV_UB_F16
 #define HMV_UB_F16 4   // the same for the fp16 kernels' drain
 #endif
+#ifndef HMV_TOUT
+#define HMV_TOUT 1     // 1: transposed-output register epilogue in the non-generic kernels (0 = the LDS-staged drain, for A/B builds)
+#endif
 
 // 256 bytes of zeros: out-of-range taps / rows DMA from here.
 static float *g_zero_page[64] = {};   // one per device ordinal
@@ -99,8 +102,9 @@ constexpr int stage_blocks(int BM, int BN, int WGM, int KB, bool full = false) {
     while (as > 1 && (TM % as != 0 || WGM * as * 32 * (BN + 4) > 2 * (BM + BN) * KB + 1024)) --as;
     return as;
 }
-constexpr int lds_floats(int BM, int BN, int WGM, int KB, bool full = false) {
+constexpr int lds_floats(int BM, int BN, int WGM, int KB, bool full = false, bool staged = true) {
     const int tile = 2 * (BM + BN) * KB;
+    if (!staged) return tile;   // register epilogue: the tile buffers are all the LDS a workgroup needs
     const int stage = WGM * stage_blocks(BM, BN, WGM, KB, full) * 32 * (BN + 4);
     return tile > stage ? tile : stage;
 }
@@ -140,12 +144,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     constexpr int AP = BM / RPS, BP = BN / RPS;
     constexpr int LDC = BN + 4;
     constexpr int AS = stage_blocks(BM, BN, WGM, KB4, RD), SR = WGM * AS * 32;
+    // Transposed output (the hot instantiations): the MFMA takes the WEIGHT rows as its A operand and the pixel rows as its B
+    // operand, so an accumulator block holds out^T: the lane is the pixel, the 16 registers are 16 output channels of that
+    // pixel.  The epilogue then needs no LDS transposition, no barrier and no staging memory: every lane adds bias / residual to
+    // its own channels and stores them as 16-byte vectors (4 consecutive fp32 channels or 8 consecutive halfs per register group).
+    constexpr bool TOUT = HMV_TOUT && !GENERIC && !RD;
     static_assert(KB == CH || KB == CH / 2, "k-step");
     // kernels that also carry the fused split main loop (selected at run time by p.x3_plane)
     constexpr bool X3CAP = F16 && KB == 64 && !GENERIC && !PARTN && !RD;
     const bool x3n = X3CAP && p.x3_plane != 0;
     static_assert(BM % RPS == 0 && BN % RPS == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
-    static_assert(TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM, KB4, RD), "epilogue staging");
+    static_assert(TOUT || (TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM, KB4, RD)), "epilogue staging");
     static_assert(!RD || (!GENERIC && !PARTN), "row-decomposed epilogue");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     T *sA = reinterpret_cast<T *>(smem);   // [2][BM][KB]
@@ -214,12 +223,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
         wptr[i] = reinterpret_cast<const T *>(p.wgt) + (size_t)(nt * BN + i * RPS + lrow) * p.ldw + EPC * kqs;
 
     f32x16 acc[TM][TN];
+    // 16-bit result rows (fp16 / (hi, lo) pairs): decides the channel order of the transposed-output accumulators (below)
+    const bool out16 = F16 && (p.out_f16 || p.out_split);
+    if constexpr (TOUT) {
+        // transposed output: a register is ONE output channel for all of the lane's pixels, so the folded-BN shift / bias is
+        // simply the accumulator's initial value (scaled up for split layers, whose epilogue scales the accumulator back)
+        const float binit = F16 ? 1.f / p.acc_scale : 1.f;   // a power of two: exact
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+        for (int b = 0; b < TN; ++b) {
+            const float *bp = p.bias + nt * BN + wn * WN + 32 * b;
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bq = *reinterpret_cast<const f32x4 *>(bp + (out16 ? 16 * (q >> 1) + 8 * kh + 4 * (q & 1) : 8 * q + 4 * kh));
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[a][b][4 * q + t] = bq[t] * binit;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    }
 
     int tnr = TN;   // 32-column blocks of this wave that hold at least one real output channel (wave-uniform)
     if constexpr (PARTN) {
@@ -285,14 +314,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     // operand fetch: lane (row l31, k-half kh) reads logical chunk 2q+kh at its swizzled position
     const int fsw = LPR == 8 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
     const T *arow = sA + (wm * WM + l31) * KB;
-    const T *brow = sB + (wn * WN + l31) * KB;
+    // Transposed output with 16-bit results: MFMA row i = (e & 3) + 8 * (e >> 2) + 4 * kh must carry channel
+    // (e & 7) + 8 * kh + 16 * (e >> 3) for a lane's registers 8j .. 8j+7 to be 8 CONSECUTIVE channels (one 16-byte store), which
+    // is the row index with bits 2 and 3 swapped: lane l31 reads weight row swap23(l31) of its block.  The swap maps each
+    // 16-lane ds_read_b128 group onto itself, so the conflict-free property of the XOR swizzle is kept.
+    const int wl31 = (TOUT && out16) ? ((l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1)) : l31;
+    const int fswb = LPR == 8 ? ((wl31 >> 1) & 7) : ((wl31 >> 2) & 3);
+    const T *brow = sB + (wn * WN + wl31) * KB;
 #define HMV_FRAGS(FA, FB, buf, q)                                                                           \
     {                                                                                                       \
         const int ch_ = ((2 * (q) + kh) ^ fsw) * EPC;                                                       \
         _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                      \
             if (!PARTN || tnr > 0) FA[a] = *reinterpret_cast<const f32x4 *>(arow + ((buf) * BM + a * 32) * KB + ch_); \
+        const int chb_ = ((2 * (q) + kh) ^ fswb) * EPC;                                                     \
         _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                      \
-            if (!PARTN || b < tnr) FB[b] = *reinterpret_cast<const f32x4 *>(brow + ((buf) * BN + b * 32) * KB + ch_); \
+            if (!PARTN || b < tnr) FB[b] = *reinterpret_cast<const f32x4 *>(brow + ((buf) * BN + b * 32) * KB + chb_); \
     }
 #define HMV_FRAG_A(FA, buf, q)                                                                              \
     {                                                                                                       \
@@ -302,7 +338,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     }
 #define HMV_FRAG_B(FB, buf, q)                                                                              \
     {                                                                                                       \
-        const int ch_ = ((2 * (q) + kh) ^ fsw) * EPC;                                                       \
+        const int ch_ = ((2 * (q) + kh) ^ fswb) * EPC;                                                      \
         _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                      \
             FB[b] = *reinterpret_cast<const f32x4 *>(brow + ((buf) * BN + b * 32) * KB + ch_);              \
     }
@@ -312,14 +348,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
             _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                  \
                 _Pragma("unroll") for (int b = 0; b < TN; ++b)                                              \
                     if (!PARTN || b < tnr)                                                                  \
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, FA[a]),    \
+                    acc[a][b] = TOUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, FB[b]),  \
+                                                                       __builtin_bit_cast(f16x8, FA[a]), acc[a][b], 0, 0, 0) \
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, FA[a]),  \
                                                                        __builtin_bit_cast(f16x8, FB[b]), acc[a][b], 0, 0, 0); \
         } else {                                                                                            \
             _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                   \
                 _Pragma("unroll") for (int a = 0; a < TM; ++a)                                              \
                     _Pragma("unroll") for (int b = 0; b < TN; ++b)                                          \
                         if (!PARTN || b < tnr)                                                              \
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a][e], FB[b][e], acc[a][b], 0, 0, 0); \
+                        acc[a][b] = TOUT ? __builtin_amdgcn_mfma_f32_32x32x2f32(FB[b][e], FA[a][e], acc[a][b], 0, 0, 0) \
+                                         : __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a][e], FB[b][e], acc[a][b], 0, 0, 0); \
         }                                                                                                   \
     }
 
@@ -395,6 +434,133 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
 #undef HMV_MFMA
     unsigned long long t1c = 0, t1r = 0;
     if (p.dbg) { t1c = __builtin_amdgcn_s_memtime(); t1r = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr (TOUT) {
+        // ---- epilogue straight from the accumulators (transposed output, see TOUT above).  Lane (l31, kh) owns pixel
+        // m = tile row l31 of each 32-pixel block a; block b's 16 registers are 16 channels of that pixel:
+        //   32-bit rows: register 4q + t  = channel 8q + 4kh + t            (4 consecutive channels per register group)
+        //   16-bit rows: register 8j + t  = channel 16j + 8kh + t           (8 consecutive channels, weight rows read swapped)
+        // The bias is already in the accumulators (their initial value); the residual of a later block is in flight while a
+        // block is finished and stored.  No LDS, no barrier: waves drain independently.
+        const int nb0 = nt * BN + wn * WN;
+        const bool has_res = p.res != nullptr;
+        const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+        const int mrow0 = mt * BM + wm * WM + l31;
+        // blocks are walked in the order g = a * TN + b; the residual of block g + PF is requested before block g is
+        // finished (ring of PF + 1 register sets, indices static after unrolling)
+        constexpr int NBLK = TM * TN, PF = (NT == 512 && TN > 1) ? TN : 1, RING = PF + 1;
+        if (!out16) {
+            const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 3) & ~3);
+            f32x4 rv[RING][4];
+#pragma unroll
+            for (int g = -PF; g < NBLK; ++g) {
+                if (g + PF < NBLK) {   // residual of block g + PF (the zero page stands in for "no residual" / rows past M)
+                    const int gg = g + PF, a = gg / TN, b = gg % TN;
+                    const int m = mrow0 + 32 * a;
+                    const bool live = has_res && m < p.M;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = nb0 + 32 * b + 8 * q + 4 * kh;
+                        const bool lv = live && col < cend;
+                        if constexpr (F16) {
+                            const _Float16 *rp = lv ? reinterpret_cast<const _Float16 *>(p.res) + (size_t)m * p.ldr + col
+                                                    : reinterpret_cast<const _Float16 *>(p.zero);
+                            const f16x4 hv = *reinterpret_cast<const f16x4 *>(rp);
+                            rv[gg % RING][q] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                            if (p.res_split) {
+                                const f16x4 l4 = *reinterpret_cast<const f16x4 *>(lv ? rp + (p.ldr >> 1) : rp);
+                                rv[gg % RING][q] += f32x4{(float)l4[0], (float)l4[1], (float)l4[2], (float)l4[3]};
+                            }
+                        } else {
+                            const float *rp = lv ? reinterpret_cast<const float *>(p.res) + (size_t)m * p.ldr + col : p.zero;
+                            rv[gg % RING][q] = *reinterpret_cast<const f32x4 *>(rp);
+                        }
+                    }
+                }
+                if (g >= 0) {
+                    const int a = g / TN, b = g % TN;
+                    const int m = mrow0 + 32 * a;
+                    float *orow = reinterpret_cast<float *>(p.out) + (size_t)m * p.ldc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = nb0 + 32 * b + 8 * q + 4 * kh;
+                        f32x4 t;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if constexpr (F16) t[j] = fmaxf(acc[a][b][4 * q + j] * p.acc_scale + rv[g % RING][q][j], lo);   // scale 1.0 unless pre-scaled weights
+                            else t[j] = fmaxf(acc[a][b][4 * q + j] + rv[g % RING][q][j], lo);
+                        }
+                        if (m < p.M && col < cend) *reinterpret_cast<f32x4 *>(orow + col) = t;
+                    }
+                }
+            }
+        } else {
+            if constexpr (F16) {
+                const int rowc = p.out_split ? p.ldc >> 1 : p.ldc;   // columns of one plane / of the row
+                const int cend = (p.fill || p.Cout + 3 >= rowc) ? rowc : ((p.Cout + 7) & ~7);
+                const int rplane = p.ldr >> 1;
+                f16x8 rh[RING][2], rl[RING][2];
+#pragma unroll
+                for (int g = -PF; g < NBLK; ++g) {
+                    if (g + PF < NBLK) {
+                        const int gg = g + PF, a = gg / TN, b = gg % TN;
+                        const int m = mrow0 + 32 * a;
+                        const bool live = has_res && m < p.M;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int col = nb0 + 32 * b + 16 * j + 8 * kh;
+                            const bool lv = live && col < cend;
+                            const _Float16 *rp = lv ? reinterpret_cast<const _Float16 *>(p.res) + (size_t)m * p.ldr + col
+                                                    : reinterpret_cast<const _Float16 *>(p.zero);
+                            rh[gg % RING][j] = *reinterpret_cast<const f16x8 *>(rp);
+                            if (p.res_split) rl[gg % RING][j] = *reinterpret_cast<const f16x8 *>(lv ? rp + rplane : rp);
+                        }
+                    }
+                    if (g >= 0) {
+                        const int a = g / TN, b = g % TN;
+                        const int m = mrow0 + 32 * a;
+                        _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int col = nb0 + 32 * b + 16 * j + 8 * kh;
+                            float t[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                float r = (float)rh[g % RING][j][u];
+                                if (p.res_split) r += (float)rl[g % RING][j][u];
+                                t[u] = fmaxf(acc[a][b][8 * j + u] * p.acc_scale + r, lo);
+                            }
+                            if (!(m < p.M && col < cend)) continue;
+                            if (p.out_split) {   // fp32 value -> (hi, lo) fp16 pair, hi + lo == value to ~2^-22
+                                f16x8 hv, lv8;
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const float c = fminf(fmaxf(t[u], -65504.f), 65504.f);
+                                    hv[u] = (_Float16)c;
+                                    lv8[u] = (_Float16)(c - (float)hv[u]);
+                                }
+                                *reinterpret_cast<f16x8 *>(orow + col) = hv;
+                                *reinterpret_cast<f16x8 *>(orow + col + rowc) = lv8;
+                            } else {
+                                f16x8 hv;
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) hv[u] = (_Float16)t[u];
+                                *reinterpret_cast<f16x8 *>(orow + col) = hv;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (p.dbg && tid == 0) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long *d = p.dbg + 8 * (size_t)blockIdx.x;
+            d[0] = t1c - t0c; d[1] = t1r - t0r; d[2] = t_entry; d[3] = t0r; d[4] = t1r;
+            d[5] = __builtin_amdgcn_s_memrealtime(); d[6] = hwid; d[7] = xcc;
+        }
+        return;
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // ---- epilogue: staged through LDS in passes of AS 32-row blocks per wave, then 16-byte row stores.
@@ -758,7 +924,8 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool /*has_res*/) {
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false>
 static hipError_t launch_one(ConvParams p, hipStream_t s) {
     static bool configured[64] = {};   // per device ordinal
-    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4, RD) * sizeof(float);
+    constexpr bool tout = HMV_TOUT && !GENERIC && !RD;   // register epilogue: no staging memory
+    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4, RD, !tout) * sizeof(float);
     auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -796,8 +963,13 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     if (!p.lda) p.lda = p.Cin;
     if (!p.ldw) p.ldw = p.Kpad;
     p.acc_scale = ldexpf(1.f, -p.acc_shift);
-    const bool generic = p.scatter || p.rg_out || p.act == ACT_GELU || p.act == ACT_LEAKY || (p.ldc & 3) ||
-                         (p.res && (p.ldr & 3));
+    bool generic = p.scatter || p.rg_out || p.act == ACT_GELU || p.act == ACT_LEAKY || (p.ldc & 3) ||
+                   (p.res && (p.ldr & 3));
+    // the register epilogue of the hot kernels moves 16-bit rows as 8-element vectors: planes that are not multiples of 8
+    // columns take the staged (generic) epilogue
+    if (HMV_TOUT && p.in_f16 && (p.out_f16 || p.out_split) &&
+        (((p.out_split ? p.ldc >> 1 : p.ldc) & 7) || (p.res && ((p.res_split ? p.ldr >> 1 : p.ldr) & 7))))
+        generic = true;
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
     if (generic && (tile == TILE_256x128 || tile == TILE_128x256 || tile == TILE_256x256 || tile == TILE_128x128_K16 ||
                     tile == TILE_128x256_K16 || tile == TILE_256x128_K16))

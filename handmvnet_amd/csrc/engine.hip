@@ -134,6 +134,7 @@ struct ProfRec {
     const char *name;
     std::string label;
     double flops;
+    double bytes;   // algorithmic HBM bytes of the launch: every operand / result element moved once
     hipEvent_t e0, e1;
 };
 
@@ -497,6 +498,10 @@ int hmv_set_tensor(hmv_handle h, const char *key, const float *host, const int64
 int hmv_finalize_weights(hmv_handle h) {
     if (!h) return HMV_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    // re-finalisation: forwards in flight and captured graphs still point at the old weight buffers
+    HIPCHK(h, hipDeviceSynchronize());
+    h->drop_graphs();
+    h->finalized = false;
     for (void *p : h->dev_allocs) (void)hipFree(p);
     h->dev_allocs.clear();
     for (auto &v : h->blocks) v.clear();
@@ -912,7 +917,17 @@ struct Runner {
             pr->label = L.label;
             // algorithmic FLOPs: the real (un-padded) reduction length; the stem's 4th channel is padding
             const double kreal = L.Kreal ? (double)L.Kreal : (double)L.K;   // real channels only (no padding FLOPs)
+            const double cout_real = L.rd_cout ? (double)L.rd_cout : (double)L.Cout;
             pr->flops = 2.0 * (double)p.M * (double)L.Cout * kreal;
+            // algorithmic bytes: each input pixel the window touches once, the weights once, residual and output rows once.
+            // A (hi, lo) pair is 4 bytes like fp32.  A strided 1x1 conv reads only the pixels it keeps.
+            const double eb_in = L.f16 ? (L.plane ? 4.0 : 2.0) : 4.0;
+            const double eb_out = (L.f16 && out_f16) ? (L.plane ? 4.0 : 2.0) : 4.0;
+            const double cin_real = kreal / (double)(L.R * L.S);   // (the row-decomposed form has R x S = 3 x 1 and Kreal = 3 * Cin)
+            const bool pointwise = L.R == 1 && L.S == 1;
+            const double in_px = (pointwise && stride > 1) ? (double)p.M : (double)N * H * W;
+            pr->bytes = in_px * cin_real * eb_in + (double)L.Cout * kreal * eb_in + (double)p.M * cout_real * eb_out +
+                        (res ? (double)p.M * cout_real * eb_in : 0.0);
             check(hipEventRecord(pr->e0, s), "hipEventRecord");
         }
         const char *kname = nullptr;
@@ -1532,6 +1547,12 @@ int hmv_profile_get(hmv_handle h, int32_t index, const char **name, const char *
     if (label) *label = r.label.c_str();
     if (ms) *ms = t;
     if (flops) *flops = r.flops;
+    return HMV_OK;
+}
+
+int hmv_profile_get_bytes(hmv_handle h, int32_t index, double *bytes) {
+    if (!h || index < 0 || (size_t)index >= h->prof_used || !bytes) return HMV_ERR_ARG;
+    *bytes = h->prof[index].bytes;
     return HMV_OK;
 }
 

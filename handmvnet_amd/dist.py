@@ -59,6 +59,13 @@ def forward_sharded(model, x: torch.Tensor, bbox=None, cam_params=None, group=No
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     total = x.shape[0]
     a, b = shard_range(total, rank, world)
-    cam = None if cam_params is None else {k: v[a:b] for k, v in cam_params.items()}
-    local = model(x[a:b], None if bbox is None else bbox[a:b], cam)
+    if b > a:
+        cam = None if cam_params is None else {k: v[a:b] for k, v in cam_params.items()}
+        local = model(x[a:b], None if bbox is None else bbox[a:b], cam)
+    else:
+        # more ranks than samples: this rank has no work, but it must still enter the collective with zero rows
+        # (the engine rejects an empty batch, and the other ranks are already waiting in the all-gather)
+        v = x.shape[1]
+        local = {"joints_cam": torch.zeros(0, 21, 3, device=x.device, dtype=torch.float32),
+                 "joints_crop_img": torch.zeros(0, v, 21, 2, device=x.device, dtype=torch.float32)}
     return gather_outputs(local, total=total, group=group)

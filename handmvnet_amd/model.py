@@ -61,8 +61,29 @@ class HandMvNet(torch.nn.Module):
     def freeze(self):
         return self.eval()
 
-    def state_dict(self, *args, **kwargs):  # noqa: D401 - mirrors nn.Module.state_dict
-        return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._weights.items())
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):  # noqa: D401 - mirrors nn.Module.state_dict
+        """nn.Module.state_dict protocol (positional destination / prefix / keep_vars as torch accepts them): the keys land
+        in `destination` under `prefix`, so a parent module's state_dict() sees them like any child's."""
+        if len(args) > 0:
+            destination = args[0]
+        if len(args) > 1:
+            prefix = args[1]
+        if destination is None:
+            destination = OrderedDict()
+        for k, v in self._weights.items():
+            destination[prefix + k] = torch.from_numpy(np.array(v))   # plain tensors either way: nothing here requires grad
+        return destination
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Called by a PARENT module's load_state_dict: pick this module's keys out of the prefixed dict."""
+        own = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        try:
+            res = self.load_state_dict(own, strict=False)
+            missing_keys.extend(prefix + k for k in res.missing_keys)
+            if strict:
+                unexpected_keys.extend(prefix + k for k in res.unexpected_keys)
+        except RuntimeError as e:
+            error_msgs.append(str(e))
 
     def load_state_dict(self, state_dict, strict: bool = True):
         """eval.py:27-52 semantics: legacy keys are remapped, strict=True raises on any
@@ -269,7 +290,8 @@ class HandMvNet(torch.nn.Module):
         if "joints_img_mask" in inputs:   # models/utils.py:123-131: masked joints are zeroed on both sides
             keep = (~inputs["joints_img_mask"].to(pred2d.device)).unsqueeze(-1)
             pred2d, gt2d = pred2d * keep, gt2d * keep
-        mpjpe, pa_mpjpe, auc_j, norm_auc_j, pck_values_j, _ = self._get_metrics(out["joints_cam"], inputs["joints_cam"])
+        gt3d = inputs["joints_cam"].to(out["joints_cam"].device)   # like the 2D ground truth: the caller's batch may sit on the host
+        mpjpe, pa_mpjpe, auc_j, norm_auc_j, pck_values_j, _ = self._get_metrics(out["joints_cam"], gt3d)
         out_metrics = {f"{mode}_mpjpe2d": PoseMetrics.mpjpe(pred2d, gt2d), f"{mode}_mpjpe": mpjpe,
                        f"{mode}_pa_mpjpe": pa_mpjpe, f"{mode}_pck_j": pck_values_j, f"{mode}_auc_j": auc_j,
                        f"{mode}_norm_auc_j": norm_auc_j}
@@ -277,15 +299,24 @@ class HandMvNet(torch.nn.Module):
             raise NotImplementedError("get_vertices needs manopth + MANO assets (joints_to_vertices.py:14-23), absent here")
         return out_metrics
 
-    def test_step(self, batch, batch_idx=0):
-        """handmvnet.py:493-517: forward + metrics.  The training losses are not part of this build, so "loss" is
-        None.  Like the reference, converts inputs["joints_cam"] / ["root_joint"] from mm to metres IN PLACE."""
+    def _eval_step(self, batch, mode):
+        """The body validation_step and test_step share in the reference (handmvnet.py:468-491 / 493-517): forward +
+        metrics.  The training losses are not part of this build, so "loss" is None.  Like the reference, converts
+        inputs["joints_cam"] / ["root_joint"] from mm to metres IN PLACE."""
         inputs = batch["data"]
         out = self.forward(inputs["rgb"], inputs["bboxes"], batch["cam_params"])
         inputs["joints_cam"] /= 1000
         if "root_joint" in inputs:
             inputs["root_joint"] /= 1000
-        return {"loss": None, "metrics": self._calculate_mpjpe(out, inputs, mode="test")}
+        return {"loss": None, "metrics": self._calculate_mpjpe(out, inputs, mode=mode)}
+
+    def validation_step(self, batch, batch_idx=0):
+        """handmvnet.py:468-491: metric keys carry the "val_" prefix (val_mpjpe is what ModelCheckpoint monitors, train.py:34)."""
+        return self._eval_step(batch, "val")
+
+    def test_step(self, batch, batch_idx=0):
+        """handmvnet.py:493-517: metric keys carry the "test_" prefix."""
+        return self._eval_step(batch, "test")
 
     # ------------------------------------------------------------------ introspection (tests / bench)
     def capture_stages(self, enable: bool = True):
@@ -332,7 +363,9 @@ class HandMvNet(torch.nn.Module):
         recs = []
         for i in range(lib.hmv_profile_count(h)):
             name, label = ctypes.c_char_p(), ctypes.c_char_p()
-            ms, fl = ctypes.c_float(), ctypes.c_double()
+            ms, fl, by = ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
             _lib.check(lib.hmv_profile_get(h, i, ctypes.byref(name), ctypes.byref(label), ctypes.byref(ms), ctypes.byref(fl)), h)
-            recs.append({"kernel": name.value.decode(), "layer": label.value.decode(), "ms": ms.value, "flops": fl.value})
+            _lib.check(lib.hmv_profile_get_bytes(h, i, ctypes.byref(by)), h)
+            recs.append({"kernel": name.value.decode(), "layer": label.value.decode(), "ms": ms.value, "flops": fl.value,
+                         "bytes": by.value})
         return recs

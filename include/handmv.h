@@ -13,6 +13,16 @@
  * the ABI; the caller owns every input/output buffer, the engine owns weights + workspace;
  * hmv_forward is asynchronous on the stream it is given (caller synchronises); a handle
  * is bound to one device and is not re-entrant; different handles are independent.
+ *
+ * Threading / stream contract.  One handle owns ONE workspace arena whose offsets every forward reuses (cached
+ * hipGraphs bake them in), plus one set of stage-capture and profiling buffers.  A handle is therefore
+ *   - not thread-safe: calls on one handle must be serialised by the caller;
+ *   - single-stream at a time: a forward may be enqueued behind another forward of the SAME handle only on the same
+ *     stream; to move a handle to another stream, synchronise (or event-order) the first stream before the next
+ *     hmv_forward.  Two forwards of one handle in flight on two streams race on the workspace.
+ * Concurrency comes from several handles (one per stream / rank), which share nothing.
+ * hmv_set_tensor + hmv_finalize_weights may be repeated on a live handle: finalisation synchronises the device and drops
+ * every cached graph before it frees the previous weight buffers.
  */
 #ifndef HANDMV_H
 #define HANDMV_H
@@ -50,7 +60,9 @@ typedef struct hmv_config {
     int32_t n_levels;      /* len(model_params["backbone_channels"]) */
     int32_t channels[4];   /* model_params["backbone_channels"] (ResNet: last level first; HRNet: highest resolution first) */
     int32_t num_views;     /* model_params["num_views"] */
-    int32_t height, width; /* frame size the plan is built for (x.shape[-2:]) */
+    int32_t height, width; /* frame size the plan is built for (x.shape[-2:]); ResNet backbones: any size >= 32 (the heat map is
+                            * ceil-chained like the reference's convs: resnet.py:216-254); HRNet: multiples of 32 (its fuse layers add
+                            * 2^k-upsampled maps, hrnet.py:194-212, which only line up at those sizes -- the reference raises otherwise) */
     int32_t image_size;    /* data_params["image_size"]   -- config constant, handmvnet.py:252 */
     int32_t heatmap_size;  /* data_params["heatmap_size"] -- config constant, handmvnet.py:252 */
     int32_t pos_enc;       /* bitmask of HMV_POS* */
@@ -117,6 +129,9 @@ int hmv_profile_count(hmv_handle h);
 /* name: kernel family = one device symbol ("conv_igemm_f32<256x256,1x1>" ...); label: layer ("layer3.2.conv2");
  * ms: duration; flops: algorithmic 2*M*N*K of that launch. */
 int hmv_profile_get(hmv_handle h, int32_t index, const char **name, const char **label, float *ms, double *flops);
+/* algorithmic HBM bytes of that launch: input pixels, weights, residual and output rows each moved once in the storage type of
+ * the arithmetic mode (what bench.py prices the launch's HBM roofline with). */
+int hmv_profile_get_bytes(hmv_handle h, int32_t index, double *bytes);
 
 /* One NHWC convolution through the engine's conv kernel (op-level parity tests).
  * in [N][H][W][Cin] device; weight OIHW host (Cin must be a multiple of 4);

@@ -16,14 +16,12 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     """The built libraries are git-ignored: on a fresh checkout build them once (hipcc cross-compiles without a GPU, gcc
     builds the oracle) -- the same thing __graft_entry__.build() does.  Never a fallback: a failed build fails the tests."""
-    lib = os.path.join(ROOT, "handmvnet_amd", "libhandmv.so")
-    oracles = [os.path.join(ROOT, "oracle", f"liboracle_hmv_{a}.so") for a in ("f32", "f64")]
-    if not os.path.exists(lib):
-        from handmvnet_amd.build import build as build_engine
-        build_engine(verbose=False)
-    if not all(os.path.exists(o) for o in oracles):
-        from oracle.oracle import build as build_oracle
-        build_oracle()
+    # both builders compare mtimes and do nothing when the binaries are newer than their sources, so calling them every
+    # session costs nothing and an edited .hip / .c can never be tested against a stale binary
+    from handmvnet_amd.build import build as build_engine
+    build_engine(verbose=False)
+    from oracle.oracle import build as build_oracle
+    build_oracle()
 
 
 @pytest.fixture(scope="session")

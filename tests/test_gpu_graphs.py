@@ -114,3 +114,47 @@ def test_module_forward_uses_graphs_in_a_steady_loop():
     assert torch.equal(out["joints_cam"], first)
     cached, replays = m.graph_stats()
     assert cached >= 1 and replays >= 4
+
+
+def test_refinalising_weights_drops_cached_graphs():
+    """The C ABI allows hmv_set_tensor + hmv_finalize_weights again on a live handle.  Finalisation frees the old weight
+    buffers, so every cached hipGraph (whose kernel arguments point at them) must go: a forward with the SAME caller
+    buffers afterwards has to compute with the NEW weights, bit-identical to an eager run of a fresh engine."""
+    import ctypes
+    from handmvnet_amd import _lib
+    from handmvnet_amd.spec import executed_keys
+    from handmvnet_amd.synth import synth_state_dict
+    m, x, bbox, cam = _model("tiny_r18")
+    bb = bbox.reshape(-1, 4).contiguous().float()
+    cam = {"intrinsic": cam["intrinsic"].reshape(-1, 4).contiguous().float()}
+    m.use_graphs(True)
+    outs = _outs(x)
+    for _ in range(3):                      # eager, capture, replay
+        _call_into(m, x, bb, cam, outs)
+    torch.cuda.synchronize()
+    old = [o.clone() for o in outs]
+    assert m.graph_stats()[0] == 1
+    # new weights into the SAME handle through the raw ABI
+    lib = _lib.load()
+    h = m._engine(x.shape[-2], x.shape[-1], 0)
+    sd2 = synth_state_dict(m.cfg, 4242)
+    for k in executed_keys(m.cfg):
+        a = np.ascontiguousarray(sd2[k], dtype=np.float32)
+        shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+        _lib.check(lib.hmv_set_tensor(h, k.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim), h)
+    _lib.check(lib.hmv_finalize_weights(h), h)
+    assert m.graph_stats()[0] == 0          # nothing stale left to replay
+    for _ in range(3):
+        _call_into(m, x, bb, cam, outs)
+    torch.cuda.synchronize()
+    # reference: a fresh eager engine with the new weights
+    from handmvnet_amd import HandMvNet
+    m2 = HandMvNet(m.train_params, m.model_params, m.data_params)
+    m2.load_state_dict(sd2, strict=True)
+    m2.use_graphs(False)
+    ref = _outs(x)
+    _call_into(m2, x, bb, cam, ref)
+    torch.cuda.synchronize()
+    for a, b, c in zip(outs, ref, old):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[1], old[1])

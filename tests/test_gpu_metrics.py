@@ -137,3 +137,14 @@ def test_evaluation_step_end_to_end(tmp_path):
     assert abs(mt["test_mpjpe"].item() - mo.mpjpe(ref_cam, gt_m) * 1000) <= dev3d + 1e-4
     dev2d = np.linalg.norm((own_crop - ref_crop) * keep, axis=-1).mean()
     assert abs(mt["test_mpjpe2d"].item() - mo.mpjpe(ref_crop * keep, gt_crop * keep)) <= dev2d + 1e-4
+    # (c) validation_step (handmvnet.py:468-491) is the same body with "val_" keys; ground truth left on the HOST is moved
+    #     to the device like the reference's Lightning batch transfer would have done
+    batch_v = {"data": {"rgb": _dev(x), "bboxes": _dev(bbox), "joints_cam": torch.from_numpy(gt_cam_mm.copy()),
+                        "root_joint": torch.zeros(1, 3), "joints_crop_img": torch.from_numpy(gt_crop.copy()),
+                        "joints_img_mask": torch.from_numpy(mask)},
+               "cam_params": {"intrinsic": _dev(intr)}}
+    rv = model.validation_step(batch_v, 0)
+    assert rv["loss"] is None and set(rv["metrics"]) == {k.replace("test_", "val_") for k in mt}
+    assert rv["metrics"]["val_mpjpe"].item() == mt["test_mpjpe"].item()
+    assert rv["metrics"]["val_pa_mpjpe"].item() == mt["test_pa_mpjpe"].item()
+    assert rv["metrics"]["val_pck_j"] == mt["test_pck_j"]

@@ -90,3 +90,34 @@ def test_flop_model_matches_survey():
     assert backbone == pytest.approx(19.23e9, rel=0.01)
     assert f["pose_net"] == pytest.approx(1.10e9, rel=0.01)
     assert f["sample_net"] == pytest.approx(1.07e9, rel=0.01)
+
+
+def test_state_dict_follows_the_nn_module_protocol():
+    """prefix / destination (keyword or positional), and a parent module's state_dict() / load_state_dict() see the keys."""
+    import torch
+    from collections import OrderedDict
+    from handmvnet_amd import HandMvNet
+    m = HandMvNet(*case_params(CASES["tiny_r18"]))
+    plain = m.state_dict()
+    assert list(plain) == list(S.state_dict_layout(m.cfg))
+    dest = OrderedDict(other=torch.zeros(1))
+    out = m.state_dict(destination=dest, prefix="net.")
+    assert out is dest and "other" in dest and all(("net." + k) in dest for k in plain)
+    assert list(m.state_dict(OrderedDict(), "p.")) == ["p." + k for k in plain]     # positional form
+
+    class Parent(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = m
+            self.extra = torch.nn.Linear(2, 2)
+
+    p = Parent()
+    sd = p.state_dict()
+    assert "extra.weight" in sd and "model.pose_net.0.weight" in sd
+    new = {k: (v + 1 if k == "model.pose_net.0.bias" else v) for k, v in sd.items()}
+    p.load_state_dict(new, strict=True)
+    assert np.allclose(m._weights["pose_net.0.bias"], plain["pose_net.0.bias"].numpy() + 1)
+    bad = dict(new)
+    del bad["model.pose_net.0.bias"]
+    with pytest.raises(RuntimeError, match="model.pose_net.0.bias"):
+        p.load_state_dict(bad, strict=True)

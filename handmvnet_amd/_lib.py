@@ -22,7 +22,7 @@ class HmvConfig(ctypes.Structure):
                 ("channels", ctypes.c_int32 * 4), ("num_views", ctypes.c_int32), ("height", ctypes.c_int32),
                 ("width", ctypes.c_int32), ("image_size", ctypes.c_int32), ("heatmap_size", ctypes.c_int32),
                 ("pos_enc", ctypes.c_int32), ("fusion_layers", ctypes.c_int32), ("decoder", ctypes.c_int32),
-                ("dtype", ctypes.c_int32), ("device", ctypes.c_int32)]
+                ("dtype", ctypes.c_int32), ("device", ctypes.c_int32), ("fusion", ctypes.c_int32)]
 
 
 class HandMvError(RuntimeError):

@@ -45,6 +45,7 @@
 //     issues the three products from one tile load (x3_plane), the cwrap loop walks hi, lo, hi as a 3x longer reduction.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "kernels.h"
@@ -75,8 +76,9 @@ static hipError_t ensure_zero_page(float **page) {
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!g_zero_page[dev]) {
-        e = hipMalloc(reinterpret_cast<void **>(&g_zero_page[dev]), 256);
-        if (e == hipSuccess) e = hipMemset(g_zero_page[dev], 0, 256);
+        // 256 bytes of zeros, then 1 KiB that masked-out lanes of the burst epilogue store into (never read)
+        e = hipMalloc(reinterpret_cast<void **>(&g_zero_page[dev]), 256 + 1024);
+        if (e == hipSuccess) e = hipMemset(g_zero_page[dev], 0, 256 + 1024);
         if (e != hipSuccess) { g_zero_page[dev] = nullptr; return e; }
     }
     *page = g_zero_page[dev];
@@ -101,6 +103,13 @@ constexpr int stage_blocks(int BM, int BN, int WGM, int KB, bool full = false) {
     int as = TM;
     while (as > 1 && (TM % as != 0 || WGM * as * 32 * (BN + 4) > 2 * (BM + BN) * KB + 1024)) --as;
     return as;
+}
+// residual burst: blocks per chunk = the largest divisor of `nblk` whose pieces fit the wave's share of the tile buffers
+constexpr int burst_blocks(int wave_bytes, int piece_count, int nblk) {
+    int cb = wave_bytes / (piece_count * 1024);
+    if (cb > nblk) cb = nblk;
+    while (cb > 1 && nblk % cb != 0) --cb;
+    return cb;
 }
 constexpr int lds_floats(int BM, int BN, int WGM, int KB, bool full = false, bool staged = true) {
     const int tile = 2 * (BM + BN) * KB;
@@ -129,8 +138,16 @@ constexpr int lds_floats(int BM, int BN, int WGM, int KB, bool full = false, boo
 // Cout = 40 fills 40 of 64 columns, and K' = 3*Cin = 120 pads to 128 instead of 360 to 384 -- 1.5x fewer MFMAs.  The
 // epilogue then sums the three column groups of horizontally neighbouring pixels, out[m][n] = sum_s G[m + s - 1][s*Cout + n],
 // which needs no halo because a tile always covers whole image rows (BM % Wo == 0, checked by launch_conv).
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p) {
+// waves per SIMD the register allocator is asked to leave room for: the 8-wave 64-accumulator tiles (256x128 / 128x256) of the fp16
+// kernels are held to 128 registers so that TWO workgroups share a CU (their load / compute / drain phases then overlap)
+#ifndef HMV_OCC2
+#define HMV_OCC2 1
+#endif
+constexpr int min_waves(int BM, int BN, int NT, bool f16, bool generic, bool rd, int KB) {
+    return (HMV_OCC2 && f16 && KB == 32 && !generic && !rd && NT == 512 && BM * BN == 256 * 128) ? 4 : (NT == 512 ? 2 : 1);
+}
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false, bool X3 = false>
+__global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, sizeof(T) == 2, GENERIC, RD, KB)) void conv_igemm(const ConvParams p) {
     constexpr bool F16 = sizeof(T) == 2;
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
     constexpr int CH = F16 ? 64 : 32;    // channel-chunk width of the packed K order
@@ -148,11 +165,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     // operand, so an accumulator block holds out^T: the lane is the pixel, the 16 registers are 16 output channels of that
     // pixel.  The epilogue then needs no LDS transposition, no barrier and no staging memory: every lane adds bias / residual to
     // its own channels and stores them as 16-byte vectors (4 consecutive fp32 channels or 8 consecutive halfs per register group).
-    constexpr bool TOUT = HMV_TOUT && !GENERIC && !RD;
+    constexpr bool TOUT = HMV_TOUT && F16 && !GENERIC && !RD;   // measured: a win on the HBM-bound fp16 kernels, not on the fp32 ones
     static_assert(KB == CH || KB == CH / 2, "k-step");
-    // kernels that also carry the fused split main loop (selected at run time by p.x3_plane)
-    constexpr bool X3CAP = F16 && KB == 64 && !GENERIC && !PARTN && !RD;
-    const bool x3n = X3CAP && p.x3_plane != 0;
+    // X3: the fused split main loop (p.x3_plane != 0) -- its own instantiation, so that its six fragment sets do not set the
+    // register budget of the plain fp16 kernels
+    constexpr bool X3CAP = X3;
+    static_assert(!X3 || (F16 && KB == 64 && !GENERIC && !PARTN && !RD), "fused split loop");
+    constexpr bool x3n = X3;
     static_assert(BM % RPS == 0 && BN % RPS == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
     static_assert(TOUT || (TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM, KB4, RD)), "epilogue staging");
     static_assert(!RD || (!GENERIC && !PARTN), "row-decomposed epilogue");
@@ -170,6 +189,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     }
     unsigned long long t_entry = 0;
     if (p.dbg) t_entry = __builtin_amdgcn_s_memrealtime();
+    if (p.stagger > 0 && (int)blockIdx.x < p.stagger_blocks) {
+        // Every workgroup of a launch runs the same phases for the same time, and the first round starts together: left alone,
+        // all CUs load, then all compute (HBM idle), then all drain (HBM saturated).  Offsetting the first round in 4 groups
+        // keeps part of the chip computing while another part moves bytes.  Later workgroups inherit the phase of the slot
+        // they take over.  Groups of 8 consecutive blocks (one per XCD) share a phase.
+        const int grp = (p.stagger_mode ? ((int)blockIdx.x >> 8) : ((int)blockIdx.x >> 3)) & 3;
+        if (grp) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)grp * (unsigned)p.stagger;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+        }
+    }
 
     // ---- XCD-aware tile assignment (bijective for any grid size)
     int mt, nt;
@@ -365,6 +395,45 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
     f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     unsigned long long t0c = 0, t0r = 0;
     if (p.dbg) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr (TOUT) {
+        // ---- software L2 prefetch.  A workgroup keeps at most one k-step of operands in flight, and its epilogue meets the
+        // residual tile cold: every phase then pays a full HBM round trip (2-3 us under load) per ~64 KB.  gfx950 has no
+        // prefetch instruction, so one 4-byte LDS-DMA load per 128-byte line (destination: a 256-byte dummy slot behind
+        // the tile buffers, never read) pulls (a) the residual tile and (b) the next k-steps of the activation rows into
+        // this XCD's L2 right now, while the first operand tiles are on their way; the real accesses later hit L2.
+        // Issued BEFORE the first DMA: loads return in order, so the waits below need no new counts.
+        if (p.prefetch) {
+            float *sdummy = smem + 2 * (BM + BN) * KB4;
+            if (p.res) {
+                constexpr int ebr = F16 ? 2 : 4;                       // residual element bytes (a split row holds two fp16 planes)
+                constexpr int lpr = (BN * ebr + 127) / 128;           // 128-byte lines per tile row and plane
+                const int planes = (F16 && p.res_split) ? 2 : 1, rowc = (F16 && p.res_split) ? p.ldr >> 1 : p.ldr;
+                for (int pl = 0; pl < planes; ++pl)
+#pragma unroll
+                    for (int L0 = 0; L0 < BM * lpr; L0 += NT) {
+                        const int L = L0 + tid, row = L / lpr, piece = L - row * lpr;
+                        const int m = mt * BM + row, col = nt * BN + piece * (128 / ebr);
+                        const bool ok = L < BM * lpr && m < p.M && col < rowc;
+                        const char *src = ok ? reinterpret_cast<const char *>(p.res) + ((size_t)m * p.ldr + (size_t)pl * rowc + col) * ebr
+                                             : reinterpret_cast<const char *>(p.zero);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                         (__attribute__((address_space(3))) void *)sdummy, 4, 0, 0);
+                    }
+            }
+            if constexpr (MODE == MODE_1X1 && !X3) {
+                // activation rows: the LPR lanes that DMA one row take one further 128-byte line of it each (k-steps 2 ..)
+                constexpr int j0 = 2 * KB * (int)sizeof(T) / 128;
+                const int off = (j0 + tid % LPR) * 128, kbytes = p.Kpad * (int)sizeof(T);
+#pragma unroll
+                for (int i = 0; i < AP; ++i) {
+                    const bool ok = astep[i] != 0 && off < kbytes && !p.cwrap;
+                    const char *src = ok ? reinterpret_cast<const char *>(aptr[i] - koff) + off : reinterpret_cast<const char *>(p.zero);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)sdummy, 4, 0, 0);
+                }
+            }
+        }
+    }
     HMV_DMA(0);
     if (nk > 1) {
         HMV_DMA(1);
@@ -445,9 +514,142 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm(const ConvParams p)
         const bool has_res = p.res != nullptr;
         const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
         const int mrow0 = mt * BM + wm * WM + l31;
+        constexpr int NBLK = TM * TN;
+        // ---- residual burst.  After the last barrier of the main loop nobody reads the tile buffers any more, so each wave
+        // turns its 1/NW share of them into a private landing zone and requests the residual of ALL its blocks at once by
+        // LDS-DMA (16 bytes per lane, the lane's own pixel and channel group as source): up to 128 KB per CU in flight with
+        // no registers spent, instead of a few loads per wave.  A block is then finished as soon as its pieces have landed
+        // (counted vmcnt: the stores issued meanwhile are younger than the DMAs they must not wait for) and read back with
+        // one ds_read_b128 per piece (lane-linear image, conflict free).  Wave-private: no barrier.
+        if (has_res && p.burst) {
+            constexpr int WLB = 2 * (BM + BN) * KB * (int)sizeof(T) / (NT / 64);   // bytes of tile buffer per wave
+            char *wl = reinterpret_cast<char *>(smem) + wave * WLB;
+            float *trash = const_cast<float *>(p.zero) + 64 + 4 * lane;   // 16 bytes per lane behind the zero page
+            if constexpr (!F16) {
+                constexpr int PC = 4, CB = burst_blocks(WLB, PC, NBLK);   // pieces / block, blocks / chunk
+                static_assert(CB >= 1 && NBLK % CB == 0, "residual landing zone");
+                const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 3) & ~3);
+#pragma unroll
+                for (int c0 = 0; c0 < NBLK; c0 += CB) {
+#pragma unroll
+                    for (int i = 0; i < CB; ++i) {
+                        const int g = c0 + i, a = g / TN, b = g % TN, m = mrow0 + 32 * a;
+#pragma unroll
+                        for (int q = 0; q < PC; ++q) {
+                            const int col = nb0 + 32 * b + 8 * q + 4 * kh;
+                            const float *src = (m < p.M && col < cend) ? reinterpret_cast<const float *>(p.res) + (size_t)m * p.ldr + col : p.zero;
+                            HMV_GLDS16(src, wl + (i * PC + q) * 1024);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < CB; ++i) {
+                        const int g = c0 + i, a = g / TN, b = g % TN, m = mrow0 + 32 * a;
+                        // pieces of block i landed when at most the (CB - 1 - i) * PC younger DMAs + the i * PC stores since are out
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((CB - 1) * PC) : "memory");
+                        float *orow = reinterpret_cast<float *>(p.out) + (size_t)m * p.ldc;
+#pragma unroll
+                        for (int q = 0; q < PC; ++q) {
+                            const int col = nb0 + 32 * b + 8 * q + 4 * kh;
+                            const f32x4 r = *reinterpret_cast<const f32x4 *>(wl + (i * PC + q) * 1024 + lane * 16);
+                            f32x4 t;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) t[j] = fmaxf(acc[a][b][4 * q + j] + r[j], lo);
+                            // every lane stores (the vmcnt arithmetic above counts on it): lanes outside the tensor hit the trash page
+                            float *dst = (m < p.M && col < cend) ? orow + col : trash;
+                            *reinterpret_cast<f32x4 *>(dst) = t;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zone is rewritten by the next chunk's DMA
+                }
+                if (p.dbg && tid == 0) {
+                    unsigned long long *d = p.dbg + 8 * (size_t)blockIdx.x;
+                    d[0] = t1c - t0c; d[1] = t1r - t0r; d[2] = t_entry; d[3] = t0r; d[4] = t1r; d[5] = __builtin_amdgcn_s_memrealtime();
+                    unsigned hwid, xcc;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                    d[6] = hwid; d[7] = xcc;
+                }
+                return;
+            } else if (out16 && (p.res_split != 0) == (p.out_split != 0)) {
+                const int rowc = p.out_split ? p.ldc >> 1 : p.ldc, rplane = p.ldr >> 1;
+                const int cend = (p.fill || p.Cout + 3 >= rowc) ? rowc : ((p.Cout + 7) & ~7);
+                auto run = [&](auto split_tag) {
+                    constexpr bool SPLIT = decltype(split_tag)::value;
+                    constexpr int PC = SPLIT ? 4 : 2, CB = burst_blocks(WLB, PC, NBLK);
+                    static_assert(CB >= 1 && NBLK % CB == 0, "residual landing zone");
+#pragma unroll
+                    for (int c0 = 0; c0 < NBLK; c0 += CB) {
+#pragma unroll
+                        for (int i = 0; i < CB; ++i) {
+                            const int g = c0 + i, a = g / TN, b = g % TN, m = mrow0 + 32 * a;
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int col = nb0 + 32 * b + 16 * j + 8 * kh;
+                                const bool lv = m < p.M && col < cend;
+                                const _Float16 *src = lv ? reinterpret_cast<const _Float16 *>(p.res) + (size_t)m * p.ldr + col
+                                                         : reinterpret_cast<const _Float16 *>(p.zero);
+                                HMV_GLDS16(src, wl + (i * PC + j) * 1024);
+                                if constexpr (SPLIT) HMV_GLDS16(lv ? src + rplane : src, wl + (i * PC + 2 + j) * 1024);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < CB; ++i) {
+                            const int g = c0 + i, a = g / TN, b = g % TN, m = mrow0 + 32 * a;
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((CB - 1) * PC) : "memory");   // PC stores per block follow PC DMAs
+                            _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc;
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int col = nb0 + 32 * b + 16 * j + 8 * kh;
+                                const f16x8 rh = *reinterpret_cast<const f16x8 *>(wl + (i * PC + j) * 1024 + lane * 16);
+                                f16x8 rl = {0, 0, 0, 0, 0, 0, 0, 0};
+                                if constexpr (SPLIT) rl = *reinterpret_cast<const f16x8 *>(wl + (i * PC + 2 + j) * 1024 + lane * 16);
+                                float t[8];
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    float r = (float)rh[u];
+                                    if constexpr (SPLIT) r += (float)rl[u];
+                                    t[u] = fmaxf(acc[a][b][8 * j + u] * p.acc_scale + r, lo);
+                                }
+                                const bool st = m < p.M && col < cend;
+                                if constexpr (SPLIT) {
+                                    f16x8 hv, lv8;
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) {
+                                        const float c = fminf(fmaxf(t[u], -65504.f), 65504.f);
+                                        hv[u] = (_Float16)c;
+                                        lv8[u] = (_Float16)(c - (float)hv[u]);
+                                    }
+                                    // every lane stores twice (the vmcnt arithmetic counts on it): lanes outside the tensor hit the trash page
+                                    _Float16 *dst = st ? orow + col : reinterpret_cast<_Float16 *>(trash);
+                                    *reinterpret_cast<f16x8 *>(dst) = hv;
+                                    *reinterpret_cast<f16x8 *>(st ? dst + rowc : dst) = lv8;
+                                } else {
+                                    f16x8 hv;
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) hv[u] = (_Float16)t[u];
+                                    *reinterpret_cast<f16x8 *>(st ? orow + col : reinterpret_cast<_Float16 *>(trash)) = hv;
+                                }
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                };
+                if (p.res_split) run(std::true_type{}); else run(std::false_type{});
+                if (p.dbg && tid == 0) {
+                    unsigned long long *d = p.dbg + 8 * (size_t)blockIdx.x;
+                    d[0] = t1c - t0c; d[1] = t1r - t0r; d[2] = t_entry; d[3] = t0r; d[4] = t1r; d[5] = __builtin_amdgcn_s_memrealtime();
+                    unsigned hwid, xcc;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                    d[6] = hwid; d[7] = xcc;
+                }
+                return;
+            }
+        }
+        // ---- register path (no residual, or a residual / output format pair the burst does not cover).
         // blocks are walked in the order g = a * TN + b; the residual of block g + PF is requested before block g is
         // finished (ring of PF + 1 register sets, indices static after unrolling)
-        constexpr int NBLK = TM * TN, PF = (NT == 512 && TN > 1) ? TN : 1, RING = PF + 1;
+        constexpr int PF = 1, RING = PF + 1;
         if (!out16) {
             const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 3) & ~3);
             f32x4 rv[RING][4];
@@ -873,9 +1075,6 @@ static const char *tile_name(const char *dtype, ConvTile t, int mode, bool partn
 }
 // fp16 has no half-step variants of the big tiles: they run as their full-step tile
 const char *conv_tile_name_f16(ConvTile t, int mode) {
-    if (t == TILE_128x256_K16) t = TILE_128x256;
-    if (t == TILE_256x128_K16) t = TILE_256x128;
-    if (t == TILE_128x128_K16) t = TILE_128x128;
     return tile_name("f16", t, mode);
 }
 const char *conv_tile_name(ConvTile t, int mode) { return tile_name("f32", t, mode); }
@@ -921,12 +1120,15 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool /*has_res*/) {
     return TILE_128x32;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false, bool X3 = false>
 static hipError_t launch_one(ConvParams p, hipStream_t s) {
+    if constexpr (!X3 && sizeof(T) == 2 && KB == 64 && !GENERIC && !PARTN && !RD) {
+        if (p.x3_plane) return launch_one<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD, true>(p, s);
+    }
     static bool configured[64] = {};   // per device ordinal
-    constexpr bool tout = HMV_TOUT && !GENERIC && !RD;   // register epilogue: no staging memory
-    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4, RD, !tout) * sizeof(float);
-    auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD>;
+    constexpr bool tout = HMV_TOUT && sizeof(T) == 2 && !GENERIC && !RD;   // register epilogue: no staging memory (+ the 256-byte prefetch dummy slot)
+    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4, RD, !tout) * sizeof(float) + (tout ? 256 : 0);
+    auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD, X3>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
@@ -937,6 +1139,7 @@ static hipError_t launch_one(ConvParams p, hipStream_t s) {
     }
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.Cout + BN - 1) / BN;
+    if (p.mtiles * p.ntiles < 4 * p.stagger_blocks) p.stagger = 0;   // too few rounds for a start-up offset to pay
     hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(64 * WGM * WGN), lds, s, p);
     return hipGetLastError();
 }
@@ -962,6 +1165,23 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     }
     if (!p.lda) p.lda = p.Cin;
     if (!p.ldw) p.ldw = p.Kpad;
+    {   // development knob: HMV_STAGGER=<10-ns ticks per phase group>[,<blocks of the first round>]
+        static int st_ticks = -1, st_blocks = 256, st_mode = 0;
+        if (st_ticks < 0) {
+            const char *e = getenv("HMV_STAGGER");
+            st_ticks = e ? atoi(e) : 0;
+            if (e) { const char *c = strchr(e, ','); if (c) { st_blocks = atoi(c + 1); c = strchr(c + 1, ','); if (c) st_mode = atoi(c + 1); } }
+        }
+        p.stagger = st_ticks;
+        p.stagger_blocks = st_blocks;
+        p.stagger_mode = st_mode;
+        static int pf = -1;   // development knob: HMV_PREFETCH=0 disables the software L2 prefetch (A/B runs)
+        if (pf < 0) { const char *e = getenv("HMV_PREFETCH"); pf = e ? atoi(e) : 0; }
+        p.prefetch = pf;
+        static int burst = -1;   // development knob: HMV_BURST=0 keeps the residual on the register-ring path (A/B runs)
+        if (burst < 0) { const char *e = getenv("HMV_BURST"); burst = e ? atoi(e) : 1; }
+        p.burst = burst;
+    }
     p.acc_scale = ldexpf(1.f, -p.acc_shift);
     bool generic = p.scatter || p.rg_out || p.act == ACT_GELU || p.act == ACT_LEAKY || (p.ldc & 3) ||
                    (p.res && (p.ldr & 3));
@@ -978,7 +1198,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     const bool dense = p.Cin % ch != 0;
     // the fused split loop exists in the non-generic fp16 kernels with a 64-element k-step, chunked modes
     if (p.x3_plane && (!p.in_f16 || generic || p.rd_cout || p.cwrap || p.x3_plane % 8 != 0 || p.Cin != 2 * p.x3_plane ||
-                       (!dense && p.x3_plane % 32 != 0) || tile == TILE_128x128_K16))
+                       (!dense && p.x3_plane % 32 != 0) || tile == TILE_128x128_K16 || tile == TILE_128x256_K16 || tile == TILE_256x128_K16))
         return hipErrorInvalidValue;
     // split operands: fp16 kernels only; the generic epilogue handles them on its vector path only
     if ((p.cwrap || p.res_split || p.out_split || p.acc_shift) &&
@@ -1056,8 +1276,11 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
             case TILE_64x64: return launch_modes<_Float16, 64, 64, 2, 2, 64>(p, one, generic, s);
             case TILE_128x128: return launch_modes<_Float16, 128, 128, 2, 2, 64>(p, one, generic, s);
             case TILE_128x128_K16: return launch_plain<_Float16, 128, 128, 2, 2, 32>(p, one, s);   // 64-byte rows, 4 blocks/CU
-            case TILE_256x128: case TILE_256x128_K16: return launch_plain<_Float16, 256, 128, 4, 2, 64>(p, one, s);
-            case TILE_128x256: case TILE_128x256_K16: return launch_plain<_Float16, 128, 256, 2, 4, 64>(p, one, s);
+            case TILE_256x128: return launch_plain<_Float16, 256, 128, 4, 2, 64>(p, one, s);
+            case TILE_128x256: return launch_plain<_Float16, 128, 256, 2, 4, 64>(p, one, s);
+            // 64-byte rows: 48 KB of tile buffers and <= 128 registers -> two 8-wave workgroups per CU
+            case TILE_256x128_K16: return launch_plain<_Float16, 256, 128, 4, 2, 32>(p, one, s);
+            case TILE_128x256_K16: return launch_plain<_Float16, 128, 256, 2, 4, 32>(p, one, s);
             case TILE_256x256: return launch_plain<_Float16, 256, 256, 2, 4, 64>(p, one, s);
             default: return hipErrorInvalidValue;
         }

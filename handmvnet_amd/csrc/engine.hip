@@ -26,6 +26,7 @@ using namespace hmv;
 namespace {
 
 constexpr int NJ = 21, HEADS = 8, DHEAD = 128, INNER = HEADS * DHEAD;
+constexpr int DHEAD_LQ = 256, INNER_LQ = HEADS * DHEAD_LQ;   // MultiHeadAttentionLearnableQuery, layers.py:241
 const int kBlocks[3][4] = {{2, 2, 2, 2}, {3, 4, 6, 3}, {3, 4, 6, 3}};
 const int kHrChannels[2][4] = {{40, 80, 160, 320}, {64, 128, 256, 512}};   // hrnet.py:430-447
 inline int cpad(int c) { return (c + 3) / 4 * 4; }   // NHWC channel stride: 16-byte pixels are all the conv kernel needs
@@ -74,6 +75,10 @@ struct HrNet {
 struct AttnLayer {
     Layer qkv, out, ff1, ff2;
     float *n1g = nullptr, *n1b = nullptr, *n2g = nullptr, *n2b = nullptr, *fg = nullptr, *fb = nullptr;
+    // learnable-query fusion (layers.py:240-301): the probe block projects only K and V from the tokens; its queries
+    // to_q(probe + PE) do not depend on the input and are computed once at load time ([21][2048])
+    Layer kv;
+    float *qprobe = nullptr;
 };
 
 // First-fit planner over one contiguous arena.  Run once "dry" to size the workspace and
@@ -150,6 +155,7 @@ struct hmv_engine {
     // derived shape facts
     int d = 0, ldt = 0, fdim = 0;
     bool paper = false;
+    bool lq = false;   // model.fusion == cross_attn_learnable_query
 
     Layer stem;
     HrNet hr;
@@ -454,10 +460,15 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     if (cfg->struct_size != (int32_t)sizeof(hmv_config)) return bad("hmv_config.struct_size mismatch (ABI)");
     if (cfg->backbone < HMV_RESNET18 || cfg->backbone > HMV_HRNET_W64) return bad("Supports only 18, 34, 50_paper (resnet) and w40, w64 (hrnet)");
     if (cfg->num_views < 1 || cfg->num_views > 48) return bad("num_views must be in [1, 48]");
-    if (cfg->fusion_layers < 1 || cfg->fusion_layers % 2 != 1) return bad("num_layers must be an odd number");
+    if (cfg->fusion != HMV_FUSION_CROSS_ATTN && cfg->fusion != HMV_FUSION_LEARNABLE_QUERY) return bad("Invalid fusion type");
+    if (cfg->fusion == HMV_FUSION_CROSS_ATTN && (cfg->fusion_layers < 1 || cfg->fusion_layers % 2 != 1))
+        return bad("num_layers must be an odd number");
     if (cfg->dtype != HMV_F32 && cfg->dtype != HMV_F16 && cfg->dtype != HMV_F32X3) { g_create_err = "dtype must be HMV_F32, HMV_F16 or HMV_F32X3"; return HMV_ERR_UNSUPPORTED; }
-    if (cfg->height < 32 || cfg->width < 32 || cfg->height % 32 || cfg->width % 32)
-        return bad("frame height/width must be positive multiples of 32");
+    // ResNet backbones take any frame size the reference's convs take (resnet.py:216-254); HRNet's fuse layers add 2^k-upsampled
+    // maps (hrnet.py:194-212), which only line up -- in the reference as here -- when every branch size is exact
+    if (cfg->height < 32 || cfg->width < 32) return bad("frame height/width must be at least 32");
+    if (cfg->backbone >= HMV_HRNET_W40 && (cfg->height % 32 || cfg->width % 32))
+        return bad("HRNet frame height/width must be multiples of 32 (its fuse layers need exact 2x branch sizes)");
     if (cfg->image_size <= 0 || cfg->heatmap_size <= 0) return bad("image_size / heatmap_size must be positive");
     const bool paper = cfg->backbone == HMV_RESNET50_PAPER;
     const bool hrnet = cfg->backbone >= HMV_HRNET_W40;
@@ -476,6 +487,7 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     h->cfg = *cfg;
     h->paper = paper;
     h->hrnet = hrnet;
+    h->lq = cfg->fusion == HMV_FUSION_LEARNABLE_QUERY;
     h->fdim = 0;
     for (int i = 0; i < cfg->n_levels; ++i) h->fdim += cfg->channels[i] / 2;
     h->d = h->fdim + ((cfg->pos_enc & HMV_POS2D) ? 2 : 0) + ((cfg->pos_enc & HMV_POS_CROP) ? 10 : 0);
@@ -681,7 +693,65 @@ int hmv_finalize_weights(hmv_handle h) {
     }
     // ---- fusion: layers.py:177-200
     const int d = h->d;
-    for (int l = 0; l < c.fusion_layers; ++l) {
+    // sinusoidal PE table (plain attribute in the reference, not in the state_dict): layers.py:134-158.  The learnable-query
+    // blocks carry their own pos_embed and always add it.
+    std::vector<float> pe_host;
+    if ((c.pos_enc & HMV_POS_SIN) || h->lq) {
+        const int T = c.num_views * NJ;
+        pe_host.resize((size_t)T * d);
+        for (int p = 0; p < T; ++p)
+            for (int cc = 0; cc < d; ++cc) {
+                const int k2 = cc & ~1;
+                const float div = expf((float)k2 * (float)(-std::log(10000.0) / (double)d));
+                const float ang = (float)p * div;
+                pe_host[(size_t)p * d + cc] = (cc & 1) ? cosf(ang) : sinf(ang);
+            }
+        h->pe = L.upload(pe_host);
+    } else {
+        h->pe = nullptr;
+    }
+    if (h->lq) {
+        // CrossAttentionFusionLearnableQuery: fusion.py:33-49; MultiHeadAttentionLearnableQuery: layers.py:240-301
+        for (int l = 0; l < 5; ++l) {
+            AttnLayer a;
+            const std::string p = "joints_late_fusion.attn_fusion." + std::to_string(l);
+            const std::string lab = "fusion_lq." + std::to_string(l);
+            const bool cross = l == 2;
+            const HostTensor *wq = L.get(p + ".to_q.weight", {INNER_LQ, d}), *wk = L.get(p + ".to_k.weight", {INNER_LQ, d}),
+                             *wv = L.get(p + ".to_v.weight", {INNER_LQ, d});
+            if (wq && wk && wv) {
+                const float *q = wq->data.data(), *k = wk->data.data(), *v = wv->data.data();
+                if (cross) {
+                    auto wt = [=](int o, int kk) -> float { return (o < INNER_LQ ? k : v)[(size_t)(o % INNER_LQ) * d + kk]; };
+                    L.finish(a.kv, lab + ".kv", h->ldt, 2 * INNER_LQ, 1, 1, d, wt, nullptr, nullptr, nullptr);
+                    const HostTensor *pr = L.get(p + ".probe", {1, NJ, d});
+                    if (pr) {   // q = to_q(probe + pe[:21]) in double, once
+                        std::vector<float> qp((size_t)NJ * INNER_LQ);
+                        for (int t = 0; t < NJ; ++t)
+                            for (int o = 0; o < INNER_LQ; ++o) {
+                                double acc = 0.0;
+                                for (int kk = 0; kk < d; ++kk)
+                                    acc += (double)(pr->data[(size_t)t * d + kk] + pe_host[(size_t)t * d + kk]) * (double)q[(size_t)o * d + kk];
+                                qp[(size_t)t * INNER_LQ + o] = (float)acc;
+                            }
+                        a.qprobe = L.upload(qp);
+                    }
+                } else {
+                    auto wt = [=](int o, int kk) -> float {
+                        const float *src = o < INNER_LQ ? q : (o < 2 * INNER_LQ ? k : v);
+                        return src[(size_t)(o % INNER_LQ) * d + kk];
+                    };
+                    L.finish(a.qkv, lab + ".qkv", h->ldt, 3 * INNER_LQ, 1, 1, d, wt, nullptr, nullptr, nullptr);
+                }
+            }
+            L.linear(a.out, lab + ".to_out", p + ".to_out.0.weight", p + ".to_out.0.bias", d, INNER_LQ);
+            L.linear(a.ff1, lab + ".ff1", p + ".ff.net.1.weight", p + ".ff.net.1.bias", DHEAD_LQ, d);
+            L.linear(a.ff2, lab + ".ff2", p + ".ff.net.4.weight", p + ".ff.net.4.bias", d, DHEAD_LQ);
+            a.fg = L.vec(p + ".ff.net.0.weight", d); a.fb = L.vec(p + ".ff.net.0.bias", d);
+            h->attn.push_back(a);
+        }
+    }
+    for (int l = 0; l < (h->lq ? 0 : c.fusion_layers); ++l) {
         AttnLayer a;
         const std::string p = "joints_late_fusion.attn_fusion." + std::to_string(l);
         const std::string lab = "fusion." + std::to_string(l);
@@ -756,21 +826,6 @@ int hmv_finalize_weights(hmv_handle h) {
         L.linear(h->fc1, "decoder.fc1", "joints_decoder.joints_fc1.weight", "joints_decoder.joints_fc1.bias", 64, d);
         L.linear(h->fc2, "decoder.fc2", "joints_decoder.joints_fc2.weight", "joints_decoder.joints_fc2.bias", 3, 64);
     }
-    // ---- sinusoidal PE table (plain attribute in the reference, not in the state_dict): layers.py:134-158
-    if (c.pos_enc & HMV_POS_SIN) {
-        const int T = c.num_views * NJ;
-        std::vector<float> pe((size_t)T * d);
-        for (int p = 0; p < T; ++p)
-            for (int cc = 0; cc < d; ++cc) {
-                const int k2 = cc & ~1;
-                const float div = expf((float)k2 * (float)(-std::log(10000.0) / (double)d));
-                const float ang = (float)p * div;
-                pe[(size_t)p * d + cc] = (cc & 1) ? cosf(ang) : sinf(ang);
-            }
-        h->pe = L.upload(pe);
-    } else {
-        h->pe = nullptr;
-    }
     if (L.rc != HMV_OK) return L.rc;
     HIPCHK(h, hipDeviceSynchronize());
     h->finalized = true;
@@ -780,27 +835,39 @@ int hmv_finalize_weights(hmv_handle h) {
 
 
 // Diagnostic: time `iters` launches of one conv shape with a chosen tile (tile < 0: engine's choice).
+// HMV_BENCH_DTYPE=f16 in the environment runs the shape on the fp16 kernels (fp16 activations / weights / residual / output).
 int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t R, int32_t S,
                    int32_t stride, int32_t pad, int32_t with_residual, int32_t tile, int32_t iters, float *avg_ms) {
     if (hipSetDevice(device) != hipSuccess) return HMV_ERR_HIP;
+    const char *edt = getenv("HMV_BENCH_DTYPE");
+    const bool f16 = edt && std::string(edt) == "f16";
+    const size_t eb = f16 ? 2 : 4;
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
-    const int K = R * S * Cin, Kpad = round_up(K, 32), Cp = round_up(Cout, 256);
+    const int K = R * S * Cin, Kpad = round_up(K, f16 ? 64 : 32), Cp = round_up(Cout, 256);
     const char *ea = getenv("HMV_BENCH_APAD"), *ew = getenv("HMV_BENCH_WPAD");
     const int lda = Cin + (ea ? atoi(ea) : 0), ldw = Kpad + (ew ? atoi(ew) : 0);
     const size_t nin = (size_t)N * H * W * lda, nout = (size_t)N * Ho * Wo * Cout, nw = (size_t)Cp * ldw;
     float *din = nullptr, *dout = nullptr, *dw = nullptr, *db = nullptr, *dres = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&din), nin * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dout), nout * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dw), nw * 4);
+    const char *esk = getenv("HMV_BENCH_SKEW");   // bytes by which the output buffer is displaced inside its allocation
+    const size_t skew = esk ? (size_t)atol(esk) : 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&din), nin * eb);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dout), nout * eb + skew);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dw), nw * eb);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&db), (size_t)Cp * 4);
-    if (e == hipSuccess && with_residual) e = hipMalloc(reinterpret_cast<void **>(&dres), nout * 4);
+    if (e == hipSuccess && with_residual) e = hipMalloc(reinterpret_cast<void **>(&dres), nout * eb);
     if (e == hipSuccess) {
         // pseudo-random (not zero: zero operands raise the clock and flatter the number)
-        std::vector<float> hbuf(std::max(std::max(nin, nw), with_residual ? nout : (size_t)1));
+        const size_t nmax = std::max(std::max(nin, nw), with_residual ? nout : (size_t)1);
+        std::vector<float> hbuf(f16 ? 0 : nmax);
+        std::vector<_Float16> hh(f16 ? nmax : 0);
         uint32_t st = 12345u;
         auto fill = [&](float *d, size_t n) {
-            for (size_t i = 0; i < n; ++i) { st = st * 1664525u + 1013904223u; hbuf[i] = ((st >> 8) * (1.0f / 8388608.0f)) - 1.0f; }
-            return hipMemcpy(d, hbuf.data(), n * 4, hipMemcpyHostToDevice);
+            for (size_t i = 0; i < n; ++i) {
+                st = st * 1664525u + 1013904223u;
+                const float v = ((st >> 8) * (1.0f / 8388608.0f)) - 1.0f;
+                if (f16) hh[i] = (_Float16)v; else hbuf[i] = v;
+            }
+            return hipMemcpy(d, f16 ? (const void *)hh.data() : (const void *)hbuf.data(), n * eb, hipMemcpyHostToDevice);
         };
         e = fill(din, nin);
         if (e == hipSuccess) e = fill(dw, nw);
@@ -809,19 +876,20 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
     }
     if (e == hipSuccess) {
         ConvParams p{};
-        p.in = din; p.wgt = dw; p.bias = db; p.res = dres; p.out = dout;
+        p.in = din; p.wgt = dw; p.bias = db; p.res = dres; p.out = reinterpret_cast<char *>(dout) + skew;
+        p.in_f16 = f16; p.out_f16 = f16; p.res_f16 = f16 && dres;
         p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
         p.R = R; p.S = S; p.stride = stride; p.pad_h = pad; p.pad_w = pad; p.K = K; p.Kpad = Kpad;
         p.M = N * Ho * Wo; p.ldc = Cout; p.ldr = Cout; p.act = ACT_RELU; p.osy = p.osx = 1;
         p.lda = lda; p.ldw = ldw;
         unsigned long long *ddbg = nullptr;
-        const int nblk_dbg = ((p.M + 127) / 128) * ((Cout + 31) / 32);
+        const int nblk_dbg = ((p.M + 63) / 64) * ((Cout + 31) / 32);
         if (getenv("HMV_BENCH_CLOCK")) {
             (void)hipMalloc(reinterpret_cast<void **>(&ddbg), (size_t)nblk_dbg * 64);
             (void)hipMemset(ddbg, 0, (size_t)nblk_dbg * 64);
             p.dbg = ddbg;
         }
-        const ConvTile t = tile < 0 ? conv_pick_tile(p.M, Cout, K) : (ConvTile)tile;
+        const ConvTile t = tile < 0 ? conv_pick_tile(p.M, Cout, K, f16, dres != nullptr) : (ConvTile)tile;
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch_conv(p, t, nullptr);
@@ -1242,15 +1310,55 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     }
     for (int i = 0; i < nkeep; ++i) R.release(lvl[i]);
     // pos2d / FoV / zero pad / PE (handmvnet.py:189-225; fusion.py:27-28)
-    LAUNCH(launch_tokens_finalize(tokens, ldt, d, h->fdim, N, V, coords, bbox, intr, c.pos_enc, h->pe,
+    LAUNCH(launch_tokens_finalize(tokens, ldt, d, h->fdim, N, V, coords, bbox, intr, c.pos_enc,
+                                  (h->lq || !(c.pos_enc & HMV_POS_SIN)) ? nullptr : h->pe,   // the learnable-query blocks add their own PE
                                   (h->capture && h->cap_tokens) ? h->cap_tokens : nullptr, s));
     R.release(coords);
 
-    // ---- CrossAttentionFusion (fusion.py:7-30; layers.py:202-237)
     float *X = tokens;
     int Tcur = V * NJ;
+    if (h->lq) {
+        // ---- CrossAttentionFusionLearnableQuery (fusion.py:33-49; MultiHeadAttentionLearnableQuery layers.py:273-301)
+        for (int l = 0; l < 5; ++l) {
+            const AttnLayer &a = h->attn[l];
+            const bool cross = l == 2;
+            const int rows = B * Tcur, Tq = cross ? NJ : Tcur, qrows = B * Tq;
+            float *xp = R.alloc((size_t)rows * ldt);                       // x = self.pos_embed(x)
+            LAUNCH(launch_add_pe(X, ldt, rows, Tcur, d, h->pe, xp, ldt, s));
+            R.release(X);
+            float *att = R.alloc((size_t)qrows * INNER_LQ);
+            float *o = R.alloc((size_t)qrows * ldt);
+            if (cross) {
+                float *kv = R.alloc((size_t)rows * 2 * INNER_LQ);
+                R.gemm(a.kv, xp, rows, kv, 2 * INNER_LQ, nullptr, 0, ACT_NONE);
+                LAUNCH(launch_attention_d256(a.qprobe, INNER_LQ, 0, kv, kv + INNER_LQ, 2 * INNER_LQ, B, Tcur, Tq, att, s));
+                R.release(kv);
+                R.gemm(a.out, att, qrows, o, ldt, nullptr, 0, ACT_NONE);   // out = to_out(att); no residual from the tokens
+            } else {
+                float *qkv = R.alloc((size_t)rows * 3 * INNER_LQ);
+                R.gemm(a.qkv, xp, rows, qkv, 3 * INNER_LQ, nullptr, 0, ACT_NONE);
+                LAUNCH(launch_attention_d256(qkv, 3 * INNER_LQ, Tcur, qkv + INNER_LQ, qkv + 2 * INNER_LQ, 3 * INNER_LQ, B, Tcur, Tq, att, s));
+                R.release(qkv);
+                R.gemm(a.out, att, qrows, o, ldt, xp, ldt, ACT_NONE);      // out = to_out(att) + x
+            }
+            R.release(att);
+            R.release(xp);
+            float *f0 = R.alloc((size_t)qrows * ldt);
+            LAUNCH(launch_layernorm(o, ldt, qrows, d, a.fg, a.fb, f0, ldt, nullptr, nullptr, nullptr, s));
+            float *f1 = R.alloc((size_t)qrows * DHEAD_LQ);
+            R.gemm(a.ff1, f0, qrows, f1, DHEAD_LQ, nullptr, 0, ACT_GELU);
+            R.release(f0);
+            float *Xn = R.alloc((size_t)qrows * ldt);
+            R.gemm(a.ff2, f1, qrows, Xn, ldt, o, ldt, ACT_NONE);          // out = ff(out) + out
+            R.release(f1);
+            R.release(o);
+            X = Xn;
+            Tcur = Tq;
+        }
+    }
+    // ---- CrossAttentionFusion (fusion.py:7-30; layers.py:202-237)
     const int half = (c.fusion_layers - 1) / 2;
-    for (int l = 0; l < c.fusion_layers; ++l) {
+    for (int l = 0; l < (h->lq ? 0 : c.fusion_layers); ++l) {
         const AttnLayer &a = h->attn[l];
         const bool cross = (l == half);
         const int Tq = cross ? NJ : Tcur, koff = cross ? NJ : 0, Tk = cross ? Tcur - NJ : Tcur;
@@ -1314,12 +1422,16 @@ int ensure_capture(hmv_engine *h, int B) {
     if (!h->capture || h->cap_batch >= B) return HMV_OK;
     const hmv_config &c = h->cfg;
     const int N = B * c.num_views;
-    const int fdiv = h->hrnet ? 4 : (h->paper ? 8 : 16);
+    // size of feats[0] by the backbones' conv arithmetic (any frame size): 3x3 s2 p1 (and 7x7 s2 p3, 1x1 s2) all give (n - 1) / 2 + 1
+    auto half_up = [](int n) { return (n - 1) / 2 + 1; };
+    int fh = half_up(half_up(c.height)), fw = half_up(half_up(c.width));           // stem: H/4
+    if (!h->hrnet) { fh = half_up(fh); fw = half_up(fw); }                         // layer2
+    if (!h->hrnet && !h->paper) { fh = half_up(fh); fw = half_up(fw); }            // layer3 of ResNet-18/34
     for (float **p : {&h->cap_feat0, &h->cap_coords, &h->cap_tokens, &h->cap_fused}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
-    h->cap_feat0_n = (size_t)N * c.channels[0] * (c.height / fdiv) * (c.width / fdiv);
+    h->cap_feat0_n = (size_t)N * c.channels[0] * fh * fw;
     h->cap_coords_n = (size_t)N * NJ * 2;
     h->cap_tokens_n = (size_t)N * NJ * h->d;
     h->cap_fused_n = (size_t)B * NJ * h->d;

@@ -49,6 +49,12 @@ struct ConvParams {
     int rd_cout;        // row-decomposed 3x3 (narrow Cout): the real channel count; Cout is then 3 * rd_cout, R = 3, S = 1
     int lda;            // input pixel stride in floats (0 = Cin)
     int ldw;            // weight row stride in floats (0 = Kpad)
+    int burst;          // residual tile by one LDS-DMA burst per wave after the main loop (filled in by launch_conv)
+    int prefetch;       // software L2 prefetch of the residual tile / later activation k-steps (filled in by launch_conv)
+    int stagger;        // start-up stagger (filled in by launch_conv): the workgroups of the first dispatch round are split into 4
+    int stagger_mode;   //   (mode 1: groups by blockIdx / 256, i.e. by dispatch round, for kernels with several workgroups per CU)
+    int stagger_blocks; //   phase groups that begin 0 / 1 / 2 / 3 x `stagger` 10-ns ticks late, so that the load / compute / drain
+                        //   phases of the 256 CUs do not march in lockstep (speed only: any placement gives the same result)
     unsigned long long *dbg;  // diagnostic builds only: per-block {shader cycles, 100 MHz ticks} of the main loop
 };
 
@@ -100,6 +106,13 @@ hipError_t launch_layernorm(const float *x, int ldx, int rows, int d, const floa
                             int ldy, const float *g2, const float *b2, float *y2, hipStream_t s);
 // softmax(q k^T / sqrt(128)) v per (sample, head); qkv rows are [q | k | v] of width 3*1024.
 hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s);
+// MultiHeadAttentionLearnableQuery (layers.py:240-301): softmax(q k^T / sqrt(256)) v per (sample, head), 8 heads x 256.
+// q rows: q + (b * q_bstride + i) * q_ld (q_bstride = 0: the same 21 probe queries for every sample); k / v rows:
+// k + (b * T + j) * kv_ld, j < T.  out [B*Tq][2048].
+hipError_t launch_attention_d256(const float *q, int q_ld, int q_bstride, const float *k, const float *v, int kv_ld, int B, int T,
+                                 int Tq, float *out, hipStream_t s);
+// y[r][c] = x[r][c] + pe[r % T][c] for c < d, 0 for d <= c < ldy (PositionalEncoding inside every learnable-query block)
+hipError_t launch_add_pe(const float *x, int ldx, int rows, int T, int d, const float *pe, float *y, int ldy, hipStream_t s);
 // Chebyshev mix: out[b][i][o] = act(sum_k sum_j Tk[k][i][j] * y[b*21+j][k*co + o] + bias[o])
 hipError_t launch_cheb_mix(const float *y, int ldy, int B, int co, const float *tk, const float *bias, int leaky,
                            float *out, int ldo, hipStream_t s);

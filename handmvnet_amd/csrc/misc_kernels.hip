@@ -606,6 +606,73 @@ hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, in
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ learnable-query fusion
+// MultiHeadAttentionLearnableQuery.forward, layers.py:273-301: x = pos_embed(x) at the top of EVERY block.
+__global__ void add_pe_kernel(const float *__restrict__ x, int ldx, int T, int d, const float *__restrict__ pe, float *__restrict__ y,
+                              int ldy, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const size_t r = i / ldy;
+        const int c = (int)(i - r * ldy);
+        y[i] = c < d ? x[r * ldx + c] + pe[(r % T) * (size_t)d + c] : 0.f;
+    }
+}
+hipError_t launch_add_pe(const float *x, int ldx, int rows, int T, int d, const float *pe, float *y, int ldy, hipStream_t s) {
+    const size_t total = (size_t)rows * ldy;
+    if (!total) return hipSuccess;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(add_pe_kernel, dim3(grid), dim3(256), 0, s, x, ldx, T, d, pe, y, ldy, total);
+    return hipGetLastError();
+}
+
+// Attention with 256-wide heads (layers.py:241, 284-291).  No release config selects this fusion, so the kernel is the
+// plain wave-per-query-row form: a lane owns 4 of the 256 head dimensions (one 16-byte vector), a score is a wave
+// reduction, softmax runs online (running max / sum are wave-uniform), K and V rows stream from L2 as 1 KiB wave loads.
+// Four query rows share each K / V row load.
+constexpr int LQ_QB = 4;
+__global__ __launch_bounds__(256) void attention_d256_kernel(const float *__restrict__ q, int q_ld, int q_bstride,
+                                                             const float *__restrict__ k, const float *__restrict__ v, int kv_ld, int T,
+                                                             int Tq, float *__restrict__ out) {
+    const int b = blockIdx.x >> 3, h = blockIdx.x & 7;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float scale = 0.0625f;   // 256 ** -0.5
+    const float *kb = k + (size_t)b * T * kv_ld + h * 256 + 4 * lane, *vb = v + (size_t)b * T * kv_ld + h * 256 + 4 * lane;
+    for (int i0 = wave * LQ_QB; i0 < Tq; i0 += 4 * LQ_QB) {
+        f32x4 qv[LQ_QB], o[LQ_QB];
+        float m[LQ_QB], l[LQ_QB];
+#pragma unroll
+        for (int r = 0; r < LQ_QB; ++r) {
+            const int i = i0 + r < Tq ? i0 + r : Tq - 1;   // rows past the end repeat the last one and are not stored
+            qv[r] = *reinterpret_cast<const f32x4 *>(q + ((size_t)b * q_bstride + i) * q_ld + h * 256 + 4 * lane);
+            o[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            m[r] = -INFINITY;
+            l[r] = 0.f;
+        }
+        for (int j = 0; j < T; ++j) {
+            const f32x4 kv = *reinterpret_cast<const f32x4 *>(kb + (size_t)j * kv_ld);
+            const f32x4 vv = *reinterpret_cast<const f32x4 *>(vb + (size_t)j * kv_ld);
+#pragma unroll
+            for (int r = 0; r < LQ_QB; ++r) {
+                const float sc = wave_sum(qv[r].x * kv.x + qv[r].y * kv.y + qv[r].z * kv.z + qv[r].w * kv.w) * scale;
+                const float mn = fmaxf(m[r], sc), alpha = expf(m[r] - mn), pj = expf(sc - mn);   // exp(-inf) = 0 on the first key
+                l[r] = l[r] * alpha + pj;
+                o[r] = o[r] * alpha + vv * pj;
+                m[r] = mn;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < LQ_QB; ++r)
+            if (i0 + r < Tq) *reinterpret_cast<f32x4 *>(out + ((size_t)b * Tq + i0 + r) * 2048 + h * 256 + 4 * lane) = o[r] * (1.f / l[r]);
+    }
+}
+hipError_t launch_attention_d256(const float *q, int q_ld, int q_bstride, const float *k, const float *v, int kv_ld, int B, int T,
+                                 int Tq, float *out, hipStream_t s) {
+    if (T <= 0 || Tq <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attention_d256_kernel, dim3(B * 8), dim3(256), 0, s, q, q_ld, q_bstride, k, v, kv_ld, T, Tq, out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ ChebConv mix
 // layers.py:387-403: sum_k T_k (X W_k) + b, the X W_k products come from one GEMM with N = 3*co.
 __global__ void cheb_mix_kernel(const float *__restrict__ y, int ldy, int co, const float *__restrict__ tk,

@@ -17,7 +17,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .spec import BACKBONE_IDS, HotPathConfig, config_from_params, executed_keys, remap_legacy_keys, state_dict_layout
+from .spec import (BACKBONE_IDS, HotPathConfig, config_from_params, executed_keys, heatmap_size_of, level_sizes,
+                   remap_legacy_keys, state_dict_layout)
 from .synth import synth_state_dict
 
 
@@ -164,6 +165,7 @@ class HandMvNet(torch.nn.Module):
         c.image_size, c.heatmap_size = cfg.image_size, cfg.heatmap_size
         c.pos_enc, c.fusion_layers, c.decoder = cfg.pos_mask, cfg.fusion_layers, int(cfg.use_gcn)
         c.dtype, c.device = self._dtype, device_index
+        c.fusion = int(cfg.learnable_query)
         h = ctypes.c_void_p()
         _lib.check(lib.hmv_create(ctypes.byref(c), ctypes.byref(h)))
         try:
@@ -216,7 +218,7 @@ class HandMvNet(torch.nn.Module):
             if bb.shape[0] != n or it.shape[0] != n:
                 raise RuntimeError("bbox / intrinsic must hold one row per frame")
         h = self._engine(hh, ww, dev.index if dev.index is not None else torch.cuda.current_device())
-        hs_h, hs_w = hh // 8, ww // 8
+        hs_h, hs_w = heatmap_size_of(self.cfg, hh, ww)   # H/8 x W/8 at the release sizes; the conv arithmetic otherwise
         out_crop = torch.empty(batch, self.num_views, 21, 2, device=dev, dtype=torch.float32)
         out_cam = torch.empty(batch, 21, 3, device=dev, dtype=torch.float32)
         out_hm = torch.empty(batch, self.num_views, 21, hs_h, hs_w, device=dev, dtype=torch.float32)
@@ -262,7 +264,7 @@ class HandMvNet(torch.nn.Module):
         h = self._engine(size, size, idx)
         out_crop = torch.empty(batch, self.num_views, 21, 2, device=dev, dtype=torch.float32)
         out_cam = torch.empty(batch, 21, 3, device=dev, dtype=torch.float32)
-        out_hm = torch.empty(batch, self.num_views, 21, size // 8, size // 8, device=dev, dtype=torch.float32)
+        out_hm = torch.empty((batch, self.num_views, 21) + tuple(heatmap_size_of(self.cfg, size, size)), device=dev, dtype=torch.float32)
         m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -328,8 +330,7 @@ class HandMvNet(torch.nn.Module):
         hh, ww, idx, batch, dt = self._last_key
         h = self._engines[(hh, ww, idx, dt)]
         n, d, cfg = batch * self.num_views, self.feat_dim, self.cfg
-        fdiv = 4 if cfg.is_hrnet else (8 if cfg.is_paper else 16)
-        shape = {"feat0": (n, cfg.backbone_channels[0], hh // fdiv, ww // fdiv), "coords_hm": (n, 21, 2),
+        shape = {"feat0": (n, cfg.backbone_channels[0]) + tuple(level_sizes(cfg, hh, ww)[0]), "coords_hm": (n, 21, 2),
                  "tokens": (batch, self.num_views * 21, d), "fused": (batch, 21, d)}[name]
         out = torch.empty(shape, device=f"cuda:{idx}", dtype=torch.float32)
         stream = torch.cuda.current_stream(out.device).cuda_stream

@@ -22,6 +22,7 @@ RESNET_BLOCKS = {"18": [2, 2, 2, 2], "34": [3, 4, 6, 3], "50_paper": [3, 4, 6, 3
 N_JOINTS = 21
 N_HEADS = 8
 DIM_HEAD = 128
+DIM_HEAD_LQ = 256   # MultiHeadAttentionLearnableQuery (layers.py:241)
 
 
 @dataclass
@@ -37,6 +38,11 @@ class HotPathConfig:
     use_gcn: bool = True
     freeze_bn: bool = False
     early_return: int = 3
+    fusion: str = "cross_attn"     # model.fusion: "cross_attn" (every release config) | "cross_attn_learnable_query"
+
+    @property
+    def learnable_query(self) -> bool:
+        return self.fusion == "cross_attn_learnable_query"
 
     @property
     def pos_mask(self) -> int:
@@ -79,9 +85,7 @@ def config_from_params(train_params: dict, model_params: dict, data_params: dict
     else:
         btype = model_params.get("backbone_type", "34")
         assert btype in ["18", "34", "50_paper"], "Supports only 18, 34, 50_paper"
-    if model_params["fusion"] != "cross_attn":
-        if model_params["fusion"] == "cross_attn_learnable_query":
-            raise NotImplementedError("cross_attn_learnable_query is SURVEY.md section 8(f) 'next'")
+    if model_params["fusion"] not in ("cross_attn", "cross_attn_learnable_query"):   # handmvnet.py:139-149
         raise NotImplementedError(f"Invalid fusion type: {model_params['fusion']}")
     ds_name = data_params.get("name", "dexycb")
     if ds_name not in ("dexycb", "ho3d", "mvhand"):
@@ -105,7 +109,44 @@ def config_from_params(train_params: dict, model_params: dict, data_params: dict
         # ResNet50_Paper hard-codes freeze_batchnorm=False (resnet.py:354)
         freeze_bn=bool(model_params.get("freeze_bn", False)) and btype in ("18", "34"),
         early_return=int(model_params.get("backbone_early_return", 3)),
+        fusion=str(model_params["fusion"]),
     )
+
+
+def _down(n: int, k: int, s: int, p: int) -> int:
+    return (n + 2 * p - k) // s + 1
+
+
+def level_sizes(cfg: HotPathConfig, h: int, w: int):
+    """[(h, w)] of the sampled feature levels in the reference's feats[] order for an h x w frame, following the conv
+    arithmetic of the backbones (resnet.py:216-254: 7x7 s2 p3, maxpool 3x3 s2 p1, 3x3 / 1x1 s2 convs -- any frame size;
+    hrnet.py:357-393: two 3x3 s2 p1 stem convs, then one more 3x3 s2 p1 per lower branch)."""
+    if cfg.is_hrnet:
+        h, w = _down(_down(h, 3, 2, 1), 3, 2, 1), _down(_down(w, 3, 2, 1), 3, 2, 1)
+        out = [(h, w)]
+        for _ in range(3):
+            h, w = _down(h, 3, 2, 1), _down(w, 3, 2, 1)
+            out.append((h, w))
+        return out[:max(len(cfg.backbone_channels), 1)]
+    h, w = _down(_down(h, 7, 2, 3), 3, 2, 1), _down(_down(w, 7, 2, 3), 3, 2, 1)   # conv1 + maxpool
+    levels = [(h, w)]                                                              # layer1
+    h, w = _down(h, 3, 2, 1), _down(w, 3, 2, 1)
+    levels.append((h, w))                                                          # layer2
+    if not cfg.is_paper:
+        h, w = _down(h, 3, 2, 1), _down(w, 3, 2, 1)
+    levels.append((h, w))                                                          # layer3 (stride 1 for 50_paper)
+    return list(reversed(levels))[:max(len(cfg.backbone_channels), 1)]
+
+
+def heatmap_size_of(cfg: HotPathConfig, h: int, w: int):
+    """(h, w) of joint_hms for an h x w frame (handmvnet.py:180): r50-paper keeps feats[0]'s size, r18/34 double it
+    (ConvTranspose2d 4x4 s2 p1), HRNet halves its highest-resolution branch (3x3 s2 p1 conv)."""
+    fh, fw = level_sizes(cfg, h, w)[0]
+    if cfg.is_hrnet:
+        return _down(fh, 3, 2, 1), _down(fw, 3, 2, 1)
+    if cfg.is_paper:
+        return fh, fw
+    return 2 * fh, 2 * fw
 
 
 def _bn(keys: "OrderedDict[str, tuple]", prefix: str, c: int, frozen: bool) -> None:
@@ -191,7 +232,27 @@ def _heads_layout(k: "OrderedDict[str, tuple]", cfg: HotPathConfig) -> None:
         _bn(k, f"sample_nets.{i}.conv.1", c // 2, False)
     d = cfg.feat_dim
     inner = N_HEADS * DIM_HEAD
-    for l in range(cfg.fusion_layers):
+    if cfg.learnable_query:
+        # CrossAttentionFusionLearnableQuery (fusion.py:33-49): always 5 MultiHeadAttentionLearnableQuery blocks
+        # (layers.py:240-301): heads 8 x 256, to_out = Sequential(Linear, Dropout), FeedForward hidden 256, no LayerNorm
+        # around the attention; the middle block owns the learnable 21-token probe.  pos_embed holds no parameters.
+        inner_lq = N_HEADS * DIM_HEAD_LQ
+        for l in range(5):
+            p = f"joints_late_fusion.attn_fusion.{l}"
+            if l == 2:
+                k[p + ".probe"] = (1, N_JOINTS, d)
+            k[p + ".to_q.weight"] = (inner_lq, d)
+            k[p + ".to_k.weight"] = (inner_lq, d)
+            k[p + ".to_v.weight"] = (inner_lq, d)
+            k[p + ".to_out.0.weight"] = (d, inner_lq)
+            k[p + ".to_out.0.bias"] = (d,)
+            k[p + ".ff.net.0.weight"] = (d,)
+            k[p + ".ff.net.0.bias"] = (d,)
+            k[p + ".ff.net.1.weight"] = (DIM_HEAD_LQ, d)
+            k[p + ".ff.net.1.bias"] = (DIM_HEAD_LQ,)
+            k[p + ".ff.net.4.weight"] = (d, DIM_HEAD_LQ)
+            k[p + ".ff.net.4.bias"] = (d,)
+    for l in range(0 if cfg.learnable_query else cfg.fusion_layers):
         p = f"joints_late_fusion.attn_fusion.{l}"
         k[p + ".to_q.weight"] = (inner, d)
         k[p + ".to_k.weight"] = (inner, d)

@@ -91,6 +91,8 @@ def _tensor(key: str, shape: tuple, seed: int, cfg: HotPathConfig) -> np.ndarray
         v = normalish(key, seed, n) * np.sqrt(gain / fan_in)
     elif len(shape) == 2:
         v = normalish(key, seed, n) * np.sqrt(1.0 / shape[1])
+    elif leaf == "probe":                                # nn.Parameter(torch.randn(1, 21, d)), layers.py:250
+        v = normalish(key, seed, n)
     else:
         raise ValueError(f"no rule for {key} {shape}")
     return v.astype(np.float32).reshape(shape)

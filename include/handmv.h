@@ -53,6 +53,11 @@ enum { HMV_DECODER_NN = 0, HMV_DECODER_GCN = 1 };
  * evaluated as hi*hi + lo*hi + hi*lo with fp32 accumulation -- three 2.5 PFLOP/s fp16 MFMAs instead of one 157 TFLOP/s fp32
  * MFMA.  Same bytes in HBM as fp32.  Heat-map logits, soft-argmax, tokens, fusion and decoder are plain fp32 as always. */
 enum { HMV_F32 = 0, HMV_F16 = 1, HMV_F32X3 = 2 };
+/* model_params["fusion"] (handmvnet.py:137-149): "cross_attn" = CrossAttentionFusion (fusion.py:7-30, every release config);
+ * "cross_attn_learnable_query" = CrossAttentionFusionLearnableQuery (fusion.py:33-49; layers.py:240-301): five blocks of
+ * heads 8 x 256, a learnable 21-token probe as the query of the middle block, a positional embedding inside every block,
+ * no LayerNorm around the attention.  fusion_layers is ignored for it (always 5), and so is HMV_POS_SIN. */
+enum { HMV_FUSION_CROSS_ATTN = 0, HMV_FUSION_LEARNABLE_QUERY = 1 };
 
 typedef struct hmv_config {
     int32_t struct_size;   /* sizeof(hmv_config), ABI guard */
@@ -70,6 +75,7 @@ typedef struct hmv_config {
     int32_t decoder;       /* HMV_DECODER_* */
     int32_t dtype;         /* HMV_F32 | HMV_F16 | HMV_F32X3 */
     int32_t device;        /* HIP device ordinal */
+    int32_t fusion;        /* HMV_FUSION_* */
 } hmv_config;
 
 /* Replaces HandMvNet.__init__ (handmvnet.py:28-125): validates the configuration and

@@ -647,6 +647,87 @@ static float *mha_block(const float *x, int B, int Tn, int d, int layer, int qle
     return out;
 }
 
+/* PositionalEncoding table value pe[p][c]: models/layers.py:134-158 (fp32 arithmetic like torch's) */
+static float pe_value(int p, int c, int d) {
+    int k2 = c & ~1;
+    float div = expf((float)k2 * (float)(-log(10000.0) / (double)d));
+    float ang = (float)p * div;
+    return (c & 1) ? cosf(ang) : sinf(ang);
+}
+
+/* MultiHeadAttentionLearnableQuery.forward: models/layers.py:273-301 (heads 8 x 256, FeedForward hidden 256, no
+ * LayerNorm around the attention).  x [B][Tn][d].  cross != 0: the queries are the learnable probe (+ PE) and the block
+ * returns [B][21][d] = ff(out) + out; else self-attention over x + PE with out = to_out(att) + (x + PE), then ff(out) + out. */
+#define DHEAD_LQ 256
+static float *mha_lq_block(const float *x, int B, int Tn, int d, int layer, int cross, int *T_out) {
+    const int inner = HEADS * DHEAD_LQ, Tq = cross ? NJ : Tn;
+    char pfx[96];
+    snprintf(pfx, sizeof pfx, "joints_late_fusion.attn_fusion.%d", layer);
+    float *xp = falloc((size_t)B * Tn * d);                 /* x = self.pos_embed(x) */
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < Tn; ++t)
+            for (int c = 0; c < d; ++c) xp[((size_t)b * Tn + t) * d + c] = x[((size_t)b * Tn + t) * d + c] + pe_value(t, c, d);
+    float *qin = xp;
+    if (cross) {                                            /* probe.repeat(batch) then pos_embed(probe) */
+        const float *probe = T("%s.probe", pfx)->data;
+        qin = falloc((size_t)B * NJ * d);
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < NJ; ++t)
+                for (int c = 0; c < d; ++c) qin[((size_t)b * NJ + t) * d + c] = probe[(size_t)t * d + c] + pe_value(t, c, d);
+    }
+    float *q = falloc((size_t)B * Tq * inner), *k = falloc((size_t)B * Tn * inner), *v = falloc((size_t)B * Tn * inner);
+    linear(qin, B * Tq, d, T("%s.to_q.weight", pfx)->data, NULL, inner, q);
+    linear(xp, B * Tn, d, T("%s.to_k.weight", pfx)->data, NULL, inner, k);
+    linear(xp, B * Tn, d, T("%s.to_v.weight", pfx)->data, NULL, inner, v);
+    float *att = falloc((size_t)B * Tq * inner);
+    const acc_t scale = (acc_t)(1.0 / sqrt((double)DHEAD_LQ));
+#pragma omp parallel for collapse(2)
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < HEADS; ++h) {
+            acc_t *dots = (acc_t *)malloc(sizeof(acc_t) * Tn);
+            for (int i = 0; i < Tq; ++i) {
+                const float *qi = q + ((size_t)b * Tq + i) * inner + h * DHEAD_LQ;
+                acc_t mx = -INFINITY;
+                for (int j = 0; j < Tn; ++j) {
+                    const float *kj = k + ((size_t)b * Tn + j) * inner + h * DHEAD_LQ;
+                    acc_t s = 0;
+                    for (int c = 0; c < DHEAD_LQ; ++c) s += (acc_t)qi[c] * (acc_t)kj[c];
+                    dots[j] = s * scale;
+                    if (dots[j] > mx) mx = dots[j];
+                }
+                acc_t sum = 0;
+                for (int j = 0; j < Tn; ++j) { dots[j] = (acc_t)exp((double)(dots[j] - mx)); sum += dots[j]; }
+                float *o = att + ((size_t)b * Tq + i) * inner + h * DHEAD_LQ;
+                for (int c = 0; c < DHEAD_LQ; ++c) {
+                    acc_t s = 0;
+                    for (int j = 0; j < Tn; ++j)
+                        s += (dots[j] / sum) * (acc_t)v[((size_t)b * Tn + j) * inner + h * DHEAD_LQ + c];
+                    o[c] = (float)s;
+                }
+            }
+            free(dots);
+        }
+    size_t tot = (size_t)B * Tq * d;
+    float *out = falloc(tot);
+    linear(att, B * Tq, inner, T("%s.to_out.0.weight", pfx)->data, T("%s.to_out.0.bias", pfx)->data, d, out);
+    if (!cross)
+        for (size_t i = 0; i < tot; ++i) out[i] += xp[i];   /* out = out + x (x already carries the PE) */
+    /* ff: LayerNorm -> Linear(d,256) -> GELU(erf) -> Linear(256,d); out = ff(out) + out */
+    float *f0 = falloc(tot), *f1 = falloc((size_t)B * Tq * DHEAD_LQ), *f2 = falloc(tot);
+    layer_norm(out, B * Tq, d, T("%s.ff.net.0.weight", pfx)->data, T("%s.ff.net.0.bias", pfx)->data, f0);
+    linear(f0, B * Tq, d, T("%s.ff.net.1.weight", pfx)->data, T("%s.ff.net.1.bias", pfx)->data, DHEAD_LQ, f1);
+    for (size_t i = 0; i < (size_t)B * Tq * DHEAD_LQ; ++i) {
+        acc_t z = (acc_t)f1[i];
+        f1[i] = (float)((acc_t)0.5 * z * ((acc_t)1 + (acc_t)erf((double)z * 0.70710678118654752440)));
+    }
+    linear(f1, B * Tq, DHEAD_LQ, T("%s.ff.net.4.weight", pfx)->data, T("%s.ff.net.4.bias", pfx)->data, d, f2);
+    for (size_t i = 0; i < tot; ++i) f2[i] += out[i];
+    if (qin != xp) free(qin);
+    free(xp); free(q); free(k); free(v); free(att); free(out); free(f0); free(f1);
+    *T_out = Tq;
+    return f2;
+}
+
 /* hand graph: models/utils.py:108-120 (adj_mx_from_edges) + constants.py:37-41 (HAND_EDGES) */
 static void hand_adjacency(float adj[NJ][NJ]) {
     static const int E[20][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {0, 5}, {5, 6}, {6, 7}, {7, 8}, {0, 9}, {9, 10},
@@ -719,6 +800,7 @@ typedef struct {
     int pos_mask;                 /* 1 pos2d | 2 crop | 4 sin */
     int fusion_layers;
     int use_gcn;
+    int fusion;                   /* 0 = cross_attn (fusion.py:7-30), 1 = cross_attn_learnable_query (fusion.py:33-49) */
 } hmvo_config;
 
 /* HandMvNet.forward: models/handmvnet.py:158-266.
@@ -853,7 +935,18 @@ int hmvo_forward(const hmvo_config *cfg, int B, int H, int W, const float *x, co
     if (tokens_out) memcpy(tokens_out, tok, sizeof(float) * (size_t)N * NJ * d);
     /* ---- CrossAttentionFusion.forward: fusion.py:26-30 ; PositionalEncoding: layers.py:134-158 */
     int Tn = V * NJ;
-    if (cfg->pos_mask & 4) {
+    if (cfg->fusion == 1) {
+        /* CrossAttentionFusionLearnableQuery.forward (fusion.py:47-49): 5 blocks, the middle one with the probe queries;
+         * every block adds its own positional embedding, so nothing is added here whatever pos_enc says */
+        float *f = tok;
+        int Tcur = Tn;
+        for (int l = 0; l < 5; ++l) {
+            float *nf = mha_lq_block(f, B, Tcur, d, l, l == 2, &Tcur);
+            free(f);
+            f = nf;
+        }
+        tok = f;
+    } else if (cfg->pos_mask & 4) {
         for (int p = 0; p < Tn; ++p)
             for (int c = 0; c < d; ++c) {
                 int k2 = c & ~1;
@@ -865,7 +958,7 @@ int hmvo_forward(const hmvo_config *cfg, int B, int H, int W, const float *x, co
     }
     int half = (cfg->fusion_layers - 1) / 2, Tcur = Tn;
     float *f = tok;
-    for (int l = 0; l < cfg->fusion_layers; ++l) {
+    for (int l = 0; l < (cfg->fusion == 1 ? 0 : cfg->fusion_layers); ++l) {
         float *nf = mha_block(f, B, Tcur, d, l, l == half ? NJ : 0, &Tcur);
         free(f);
         f = nf;

@@ -19,7 +19,8 @@ _BACKBONE = {"18": 0, "34": 1, "50_paper": 2, "w40": 3, "w64": 4}
 class _Cfg(ctypes.Structure):
     _fields_ = [("backbone", ctypes.c_int), ("n_levels", ctypes.c_int), ("channels", ctypes.c_int * 4),
                 ("num_views", ctypes.c_int), ("image_size", ctypes.c_int), ("heatmap_size", ctypes.c_int),
-                ("pos_mask", ctypes.c_int), ("fusion_layers", ctypes.c_int), ("use_gcn", ctypes.c_int)]
+                ("pos_mask", ctypes.c_int), ("fusion_layers", ctypes.c_int), ("use_gcn", ctypes.c_int),
+                ("fusion", ctypes.c_int)]
 
 
 def build(force: bool = False) -> None:
@@ -103,6 +104,7 @@ class Oracle:
             c.channels[i] = ch
         c.num_views, c.image_size, c.heatmap_size = cfg.num_views, cfg.image_size, cfg.heatmap_size
         c.pos_mask, c.fusion_layers, c.use_gcn = cfg.pos_mask, cfg.fusion_layers, int(cfg.use_gcn)
+        c.fusion = 1 if getattr(cfg, "learnable_query", False) else 0
         self._c = c
 
     @property
@@ -118,7 +120,8 @@ class Oracle:
         intrinsic = np.ascontiguousarray(intrinsic, dtype=np.float32)
         B, V, _, H, W = x.shape
         assert V == cfg.num_views
-        hs, ws = H // 8, W // 8
+        from handmvnet_amd.spec import heatmap_size_of, level_sizes   # shape arithmetic only (no engine code involved)
+        hs, ws = heatmap_size_of(cfg, H, W)
         d = cfg.feat_dim
         out = {
             "joints_crop_img": np.zeros((B, V, 21, 2), np.float32),
@@ -127,8 +130,8 @@ class Oracle:
         }
         st = {}
         if stages:
-            fdiv = 4 if cfg.is_hrnet else (8 if cfg.is_paper else 16)
-            st = {"feat0": np.zeros((B * V, cfg.backbone_channels[0], H // fdiv, W // fdiv), np.float32),
+            fh, fw = level_sizes(cfg, H, W)[0]
+            st = {"feat0": np.zeros((B * V, cfg.backbone_channels[0], fh, fw), np.float32),
                   "coords_hm": np.zeros((B * V, 21, 2), np.float32),
                   "tokens": np.zeros((B, V * 21, d), np.float32),
                   "fused": np.zeros((B, 21, d), np.float32)}

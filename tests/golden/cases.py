@@ -35,6 +35,18 @@ CASES = {
     # non-power-of-two input, config constants that differ from the tensor shapes (handmvnet.py:252 quirk)
     "r50_odd_96": dict(bt="50_paper", ch=[1024], V=5, B=1, size=96, pos=ALL_POS, gcn=True, wseed=9, iseed=19,
                        image_size=200, heatmap_size=32),
+    # model.fusion = cross_attn_learnable_query: 5 MultiHeadAttentionLearnableQuery blocks, heads 8 x 256,
+    # learnable 21-token probe.  The reference's HandMvNet.forward passes add_pos= to it and dies with a TypeError
+    # (handmvnet.py:227 vs fusion.py:47); the fixture generator calls the module without that keyword (ref_harness.py).
+    "r50_lq": dict(bt="50_paper", ch=[1024], V=3, B=2, size=64, pos=ALL_POS, gcn=True, wseed=21, iseed=31,
+                   fusion="cross_attn_learnable_query"),
+    "r18_lq_wocam": dict(bt="18", ch=[256, 128, 64], V=2, B=1, size=64, pos=["pos2d"], gcn=False, wseed=22, iseed=32,
+                         fusion="cross_attn_learnable_query"),
+    # frame sizes that are not multiples of 32 (the reference's convs take any size: resnet.py:216-254)
+    "r50_200": dict(bt="50_paper", ch=[1024], V=2, B=1, size=200, pos=ALL_POS, gcn=True, wseed=23, iseed=33,
+                    image_size=200, heatmap_size=25),
+    "r18_100": dict(bt="18", ch=[256, 128, 64], V=2, B=1, size=100, pos=ALL_POS, gcn=True, wseed=24, iseed=34,
+                    image_size=100, heatmap_size=14),
 }
 
 
@@ -44,7 +56,7 @@ def case_params(spec: dict):
     mp = {"num_views": spec["V"], "backbone": "hrnet" if spec["bt"].startswith("w") else "resnet", "backbone_type": spec["bt"],
           "backbone_pretrained_path": "",
           "backbone_channels": list(spec["ch"]), "backbone_pretrained": False, "backbone_early_return": 3,
-          "freeze_bn": bool(spec.get("freeze_bn", False)), "pos_enc": list(spec["pos"]), "fusion": "cross_attn",
+          "freeze_bn": bool(spec.get("freeze_bn", False)), "pos_enc": list(spec["pos"]), "fusion": spec.get("fusion", "cross_attn"),
           "fusion_layers": int(spec.get("fusion_layers", 5)), "use_gcn": bool(spec["gcn"])}
     dp = {"batch_size": spec["B"], "image_size": int(spec.get("image_size", spec["size"])),
           "heatmap_size": int(spec.get("heatmap_size", spec["size"] // 8)), "name": "ho3d"}

@@ -83,4 +83,11 @@ def build_reference_model(train_params: dict, model_params: dict, data_params: d
     sd = {k: torch.from_numpy(v.copy()) if v.ndim else torch.tensor(int(v)) for k, v in state_dict_np.items()}
     model.load_state_dict(sd, strict=True)
     model.freeze()
+    if mp.get("fusion") == "cross_attn_learnable_query":
+        # HandMvNet.forward (handmvnet.py:227) calls joints_late_fusion(x, add_pos=...), a keyword that
+        # CrossAttentionFusionLearnableQuery.forward(self, x) (fusion.py:47) does not take: the reference raises TypeError.
+        # The fixtures pin the module itself: same module, same weights, called the only way its signature allows.
+        lq = model.joints_late_fusion
+        orig = lq.forward
+        lq.forward = lambda x, add_pos=True: orig(x)
     return model

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_matches_header_and_is_validated():
     lib = _lib.load()
-    assert ctypes.sizeof(_lib.HmvConfig) == 17 * 4
+    assert ctypes.sizeof(_lib.HmvConfig) == 18 * 4          # incl. the fusion kind added for cross_attn_learnable_query
     h = ctypes.c_void_p()
     c = _lib.HmvConfig()
     c.struct_size = 12                      # wrong ABI size is rejected before anything touches HIP

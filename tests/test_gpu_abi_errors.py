@@ -24,6 +24,7 @@ def _cfg(lib_mod, cfg, hh, ww, **over):
     c.num_views, c.height, c.width = cfg.num_views, hh, ww
     c.image_size, c.heatmap_size = cfg.image_size, cfg.heatmap_size
     c.pos_enc, c.fusion_layers, c.decoder, c.dtype, c.device = cfg.pos_mask, cfg.fusion_layers, int(cfg.use_gcn), 0, 0
+    c.fusion = int(cfg.learnable_query)
     for k, v in over.items():
         setattr(c, k, v)
     return c
@@ -41,7 +42,8 @@ def test_create_rejects_bad_configurations():
     cfg, _, sd, _, _ = load_case("tiny_r18")
     h = ctypes.c_void_p()
     for over, code, text in [({"struct_size": 8}, ARG, b"struct_size"), ({"backbone": 9}, ARG, b"Supports only"),
-                             ({"fusion_layers": 4}, ARG, b"odd number"), ({"height": 100}, ARG, b"multiples of 32"),
+                             ({"fusion_layers": 4}, ARG, b"odd number"), ({"height": 16}, ARG, b"at least 32"),
+                             ({"fusion": 7}, ARG, b"Invalid fusion type"), ({"backbone": 3, "height": 100}, ARG, b"multiples of 32"),
                              ({"num_views": 0}, ARG, b"num_views"), ({"dtype": 7}, UNSUPPORTED, b"dtype"),
                              ({"device": 99}, ARG, b"device ordinal")]:
         rc = lib.hmv_create(ctypes.byref(_cfg(_lib, cfg, 64, 64, **over)), ctypes.byref(h))

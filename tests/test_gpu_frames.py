@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 import torch
 
+from test_gpu_parity import fp16_bounds
 from helpers import load_case, rel_l2
 from oracle import frames_oracle as fo
 
@@ -76,7 +77,9 @@ def test_forward_frames_equals_forward_on_prepared_batch(name, mode):
     fused = m.forward_frames(_dev(frames), _dev(boxes), cam, image_size=size)
     torch.cuda.synchronize()
     assert set(fused) == {"joints_crop_img", "joints_cam", "heatmap"}
-    tol = 2e-3 if half else 1e-4
+    # fp16 storage: the two paths' inputs differ by ~5e-6, which is enough to flip fp16 roundings, so they land a noise
+    # floor apart (tests/golden/fp16_noise.json, measured on the reference itself; see test_gpu_parity.py)
+    tol = fp16_bounds(name)["joints_cam"] if half else 1e-4
     assert rel_l2(fused["joints_cam"].cpu().numpy(), two_step["joints_cam"].cpu().numpy()) < tol
     assert np.abs(fused["joints_crop_img"].cpu().numpy() - two_step["joints_crop_img"].cpu().numpy()).max() < (0.5 if half else 0.02)
     assert rel_l2(fused["heatmap"].cpu().numpy(), two_step["heatmap"].cpu().numpy()) < (5e-3 if half else 1e-4)

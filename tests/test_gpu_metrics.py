@@ -145,6 +145,7 @@ def test_evaluation_step_end_to_end(tmp_path):
                "cam_params": {"intrinsic": _dev(intr)}}
     rv = model.validation_step(batch_v, 0)
     assert rv["loss"] is None and set(rv["metrics"]) == {k.replace("test_", "val_") for k in mt}
-    assert rv["metrics"]["val_mpjpe"].item() == mt["test_mpjpe"].item()
-    assert rv["metrics"]["val_pa_mpjpe"].item() == mt["test_pa_mpjpe"].item()
+    # (the host-side /1000 of the ground truth may differ from the device's by an ulp)
+    assert rv["metrics"]["val_mpjpe"].item() == pytest.approx(mt["test_mpjpe"].item(), rel=1e-5)
+    assert rv["metrics"]["val_pa_mpjpe"].item() == pytest.approx(mt["test_pa_mpjpe"].item(), rel=1e-5)
     assert rv["metrics"]["val_pck_j"] == mt["test_pck_j"]

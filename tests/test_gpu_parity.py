@@ -10,6 +10,9 @@ are held to 2e-4 and heat-map coordinates to 0.05 heat-map px.
 """
 import ctypes
 
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -219,14 +222,21 @@ def test_conv_kernel_random_shapes(dtype, tol):
     print("worst", dtype, worst)
 
 
-def test_full_size_properties():
-    """BASELINE.json configs[2] size (B=32, V=8, 256x256, r50-paper): determinism and
-    batch-independence (sample i alone == sample i inside the batch, bit for bit)."""
+@pytest.mark.parametrize("mode", ["f32", "f32x3", "f16"])
+def test_full_size_properties(mode):
+    """BASELINE.json configs[2] / configs[4] size (B=32, V=8, 256x256, r50-paper) in every arithmetic mode (their tile rules
+    differ): determinism and batch-independence (sample i alone == sample i inside the batch, bit for bit); and sample 0
+    against the f64 CPU oracle at the mode's own bar."""
     from handmvnet_amd import HandMvNet
     from handmvnet_amd.synth import synth_inputs
+    from oracle.oracle import Oracle
     cfg, (tp, mp, dp), sd, _, _ = load_case("cfg3s_r50_v8_256")
     m = HandMvNet(tp, mp, dp)
     m.load_state_dict(sd)
+    if mode == "f16":
+        m.half()
+    elif mode == "f32x3":
+        m.float32x3()
     x, bbox, intr = synth_inputs(cfg, 32, 99, 256)
     dev = torch.device("cuda:0")
     xt, bt, it = torch.from_numpy(x).to(dev), torch.from_numpy(bbox).to(dev), torch.from_numpy(intr).to(dev)
@@ -244,6 +254,33 @@ def test_full_size_properties():
     # soft-argmax coordinates live inside the heat map
     hs = 32
     assert (a["joints_crop_img"] >= -1e-3).all() and (a["joints_crop_img"] <= (hs - 1) * 8 + 1e-3).all()
+    # one sample of the full-size batch against the f64 oracle (~5 s of CPU): the fp32-grade modes at the north-star bar,
+    # the fp16 path at its noise-floor bound (same model as the cfg3s fixture)
+    ref = Oracle(cfg, sd, "f64").forward(x[:1], bbox[:1], intr[:1])
+    cam = rel_l2(a["joints_cam"][0].cpu().numpy(), ref["joints_cam"][0])
+    assert cam <= (fp16_bounds("cfg3s_r50_v8_256")["joints_cam"] if mode == "f16" else TOL_CAM), (mode, cam)
+
+
+def test_cfg2_full_batch_against_the_oracle():
+    """BASELINE.json configs[1] at its REAL batch (B=8, V=4, 256x256, ResNet-18; the fixture of that shape is B=2): every
+    sample against the f64 CPU oracle, plus batch independence."""
+    from handmvnet_amd import HandMvNet
+    from handmvnet_amd.synth import synth_inputs
+    from oracle.oracle import Oracle
+    cfg, (tp, mp, dp), sd, _, _ = load_case("cfg2s_r18_v4_256")
+    m = HandMvNet(tp, mp, dp)
+    m.load_state_dict(sd)
+    x, bbox, intr = synth_inputs(cfg, 8, 123, 256)
+    dev = torch.device("cuda:0")
+    xt, bt, it = torch.from_numpy(x).to(dev), torch.from_numpy(bbox).to(dev), torch.from_numpy(intr).to(dev)
+    got = m(xt, bt, {"intrinsic": it})
+    torch.cuda.synchronize()
+    ref = Oracle(cfg, sd, "f64").forward(x, bbox, intr)
+    assert rel_l2(got["joints_cam"].cpu().numpy(), ref["joints_cam"]) <= TOL_CAM
+    assert np.abs(got["joints_crop_img"].cpu().numpy() - ref["joints_crop_img"]).max() <= 0.05 * 8
+    assert rel_l2(got["heatmap"].cpu().numpy(), ref["heatmap"]) <= TOL_STAGE
+    one = m(xt[5:6], bt[5:6], {"intrinsic": it[5:6]})
+    assert torch.equal(one["joints_cam"][0], got["joints_cam"][5])
 
 
 def test_state_dict_errors_match_reference_behaviour():
@@ -271,17 +308,32 @@ def test_state_dict_errors_match_reference_behaviour():
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json configs[4]: the fp16 path (model.half()): conv stack in fp16 storage + fp16 MFMA
 # with fp32 accumulation; heat-map logits, soft-argmax, tokens, fusion and decoder stay fp32.
-# Its tolerance is stated SEPARATELY from the fp32 north-star bar (hard part 1):
-#   * dense tensors (backbone features, heat maps): <= 3e-3 rel-L2 (fp16 has a 2^-11 mantissa and the
-#     rounding noise of ~50 layers accumulates to ~9e-4 measured);
-#   * heat-map coordinates: median error <= 0.02 px, and at most 6 % of the coordinates may move by more
-#     than half a pixel -- soft_argmax_2d multiplies logits by 1000, so a 1e-3 heat-map error flips the
-#     winner of near-tied peaks (the synthetic random-weight heat maps have many near ties; measured
-#     flip rate 0-2.8 %);
-#   * joints_cam: <= 0.15 rel-L2, dominated by exactly those flips (measured 5e-4 .. 7.6e-2).
+# Its tolerance is stated SEPARATELY from the fp32 north-star bar (hard part 1) and is tied to the
+# NOISE FLOOR OF fp16 STORAGE MEASURED ON THE REFERENCE ITSELF: tests/golden/make_fp16_noise.py runs the real reference
+# with exactly the roundings any fp16-storage implementation must make (frames, conv weights, every conv+BN unit's and
+# every residual block's output -> fp16; fp32 accumulation) and records, per case, how far THAT lands from the unrounded
+# reference (tests/golden/fp16_noise.json: heat map 4e-4..1.1e-3 rel-L2, 0-3 % of the coordinates moved by > 1/2 px because
+# soft_argmax_2d multiplies the logits by 1000, joints_cam 1e-3..1.2e-1 because the random-weight fusion transformer
+# amplifies token noise ~50x).  The same script shows that keeping the last bottleneck + pose_net (or even all of
+# layer3) in fp32-grade arithmetic does not move these numbers (flip rate 3.0 % -> 2.5 % -> 0.9 %): the noise is injected
+# in layer1/2 already, so a mixed-precision tail is not a remedy and is not built.  The engine is held to:
+#   * heat map:           <= 2 x the floor's rel-L2 (+ 2e-4)
+#   * coordinates:        median <= 0.02 px; fraction moved by > 1/2 px <= floor + 2 %
+#   * joints_cam:         <= 3 x the floor's rel-L2 (+ 2e-3)
+# i.e. "as close to the fp32 reference as fp16 storage lets ANY implementation be, within a small factor".  The
+# fp32-grade alternative on the same matrix cores is HMV_F32X3 (next test), which meets the fp32 bars.
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["tiny_r50", "tiny_r18", "cfg1_r50_v4_128", "cfg2s_r18_v4_256", "cfg3s_r50_v8_256",
-                                  "r50_wocam_nn", "r34_onelevel", "r18_single_view", "hr40_tiny", "hr40_v4_128", "hr64_tiny"])
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp16_noise.json")) as _f:
+    FP16_NOISE = json.load(_f)["cases"]
+
+
+def fp16_bounds(name):
+    fl = FP16_NOISE[name]
+    return {"heatmap": 2.0 * fl["heatmap_rel_l2"] + 2e-4, "flip": fl["coord_flip_frac"] + 0.02,
+            "joints_cam": 3.0 * fl["joints_cam_rel_l2"] + 2e-3}
+
+
+@pytest.mark.parametrize("name", list(CASES))
 def test_fp16_path_within_its_stated_tolerance(name):
     m, cfg, sd, (x, bbox, intr), fx = _model(name)
     m.half()
@@ -290,12 +342,13 @@ def test_fp16_path_within_its_stated_tolerance(name):
     hm = rel_l2(got["heatmap"].reshape(-1)[fx["heatmap_idx"]], fx["heatmap_val"])
     dc = np.abs(got["coords_hm"] - fx["coords_hm"])
     cam = rel_l2(got["joints_cam"], fx["joints_cam"])
+    bound = fp16_bounds(name)
     rep = {"feat0": feat, "heatmap": hm, "coord_median_px": float(np.median(dc)), "coord_flip_frac": float((dc > 0.5).mean()),
-           "joints_cam": cam}
+           "joints_cam": cam, "bounds": bound}
     print(name, rep)
-    assert feat <= 3e-3 and hm <= 3e-3, rep
-    assert rep["coord_median_px"] <= 0.02 and rep["coord_flip_frac"] <= 0.06, rep
-    assert cam <= 0.15, rep
+    assert feat <= 2e-3 and hm <= bound["heatmap"], rep
+    assert rep["coord_median_px"] <= 0.02 and rep["coord_flip_frac"] <= bound["flip"], rep
+    assert cam <= bound["joints_cam"], rep
     assert np.isfinite(got["joints_cam"]).all()
     # and the fp16 engine really is a different numerical path from the fp32 one
     m.float()
@@ -312,7 +365,7 @@ def test_fp16_path_within_its_stated_tolerance(name):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["tiny_r50", "cfg1_r50_v4_128", "cfg3s_r50_v8_256", "r50_wocam_nn", "r50_odd_96",
                                   "hr40_tiny", "hr40_v4_128", "hr64_tiny", "tiny_r18", "cfg2s_r18_v4_256", "r34_onelevel",
-                                  "r18_frozen_nosin", "r18_single_view", "r18_13views"])
+                                  "r18_frozen_nosin", "r18_single_view", "r18_13views", "r50_lq", "r18_lq_wocam", "r50_200", "r18_100"])
 def test_split_precision_path_meets_the_fp32_bar(name):
     m, cfg, sd, (x, bbox, intr), fx = _model(name)
     m.float32x3()

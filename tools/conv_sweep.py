@@ -42,7 +42,10 @@ def main():
         Ho = (H + 2 * pad - k) // st + 1
         kreal = k * k * (3 if Cin == 4 else Cin)
         fl = 2.0 * n_img * Ho * Ho * Cout * kreal
-        line = f"{name:24s} {fl / 1e9:8.1f} GF x{cnt}"
+        eb = 2 if os.environ.get("HMV_BENCH_DTYPE") == "f16" else 4
+        in_px = n_img * Ho * Ho if (k == 1 and st > 1) else n_img * H * H
+        nbytes = eb * (in_px * (3 if Cin == 4 else Cin) + Cout * kreal + n_img * Ho * Ho * Cout * (2 if res else 1))
+        line = f"{name:24s} {fl / 1e9:8.1f} GF {nbytes / 1e6:7.1f} MB x{cnt}"
         for t in tiles:
             ms = ctypes.c_float()
             rc = lib.hmv_bench_conv(0, n_img, H, H, Cin, Cout, k, k, st, pad, res, t, 5, ctypes.byref(ms))
@@ -51,7 +54,7 @@ def main():
                 continue
             tf = fl / (ms.value * 1e-3) / 1e12
             tot_ms[t] += ms.value * cnt
-            line += f" | t{t}: {ms.value:7.3f} ms {tf:6.1f} TF"
+            line += f" | t{t}: {ms.value:7.3f} ms {tf:6.1f} TF {nbytes / (ms.value * 1e-3) / 1e12:4.2f} TB/s"
             rows.append({"layer": name, "tile": t, "ms": ms.value, "tflops": tf, "count": cnt})
         tot_fl += fl * cnt
         print(line, flush=True)

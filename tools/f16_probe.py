@@ -6,6 +6,8 @@ for q in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 from helpers import load_case, rel_l2
 from handmvnet_amd import HandMvNet
 from cases import CASES
+import json
+NOISE = json.load(open(os.path.join(ROOT, "tests", "golden", "fp16_noise.json")))["cases"]
 for name in CASES:
     cfg, (tp, mp, dp), sd, (x, bbox, intr), fx = load_case(name)
     m = HandMvNet(tp, mp, dp); m.load_state_dict(sd); (m.float32x3() if os.environ.get("HMV_PROBE_MODE") == "f32x3" else m.half()); m.capture_stages(True)
@@ -16,4 +18,4 @@ for name in CASES:
     coords = m.read_stage("coords_hm").cpu().numpy(); feat = m.read_stage("feat0").cpu().numpy().reshape(-1)
     dc = np.abs(coords - fx["coords_hm"]); 
     hm = out["heatmap"].cpu().numpy().reshape(-1)
-    print(f"{name:22s} joints_cam rel {rel_l2(cam, fx['joints_cam']):.3e}  feat0 rel {rel_l2(feat[fx['feat0_idx']], fx['feat0_val']):.3e}  hm rel {rel_l2(hm[fx['heatmap_idx']], fx['heatmap_val']):.3e}  coords: max {dc.max():.3f} px, >0.5px: {(dc>0.5).mean()*100:.1f}%  median {np.median(dc):.4f}")
+    print(f"{name:22s} joints_cam rel {rel_l2(cam, fx['joints_cam']):.3e}  feat0 rel {rel_l2(feat[fx['feat0_idx']], fx['feat0_val']):.3e}  hm rel {rel_l2(hm[fx['heatmap_idx']], fx['heatmap_val']):.3e}  coords: max {dc.max():.3f} px, >0.5px: {(dc>0.5).mean()*100:.1f}%  median {np.median(dc):.4f}  | floor: {NOISE.get(name)}")

@@ -324,6 +324,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
             wptr[i] += KB;                                                                                  \
         }                                                                                                   \
         ck += KB;                                                                                           \
+        if (MODE == MODE_1X1 && p.in2 && ck == p.ksplit) { /* concatenated reduction: the rest comes from the second source */ \
+            _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                \
+                const int m_ = mt * BM + i * RPS + lrow;                                                    \
+                if (m_ < p.M) {                                                                             \
+                    const int n_ = m_ / HoWo, rem_ = m_ - n_ * HoWo, ho_ = rem_ / p.Wo, wo_ = rem_ - ho_ * p.Wo; \
+                    aptr[i] = reinterpret_cast<const T *>(p.in2) + ((size_t)n_ * p.H2 * p.W2 +            \
+                              (size_t)(ho_ * p.stride2) * p.W2 + wo_ * p.stride2) * p.lda2 + koff;          \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
         if (F16 && MODE == MODE_1X1 && ck == p.cwrap) { /* split operands: after hi, lo walk the hi plane again */ \
             _Pragma("unroll") for (int i = 0; i < AP; ++i) if (astep[i]) aptr[i] -= p.cwrap;                \
         }                                                                                                   \
@@ -1191,6 +1201,9 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         (((p.out_split ? p.ldc >> 1 : p.ldc) & 7) || (p.res && ((p.res_split ? p.ldr >> 1 : p.ldr) & 7))))
         generic = true;
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
+    if (p.in2 && (!one || p.stride != 1 || p.up || p.cwrap || p.x3_plane || p.rd_cout || p.ksplit <= 0 || p.ksplit >= p.K ||
+                  p.ksplit % (p.in_f16 ? 64 : 32) != 0 || p.Cin % (p.in_f16 ? 64 : 32) != 0))
+        return hipErrorInvalidValue;   // the second source exists in the chunked 1x1 mode only
     if (generic && (tile == TILE_256x128 || tile == TILE_128x256 || tile == TILE_256x256 || tile == TILE_128x128_K16 ||
                     tile == TILE_128x256_K16 || tile == TILE_256x128_K16))
         tile = TILE_128x128;   // the rarely used epilogue paths exist only for the 4-wave tiles

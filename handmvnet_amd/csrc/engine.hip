@@ -57,6 +57,10 @@ struct Block {
     Layer c1, c2, c3, ds;
     bool has_ds = false;
     int stride = 1;
+    // Bottleneck with a downsample branch: conv3 + BN3 and downsample conv + BN as ONE GEMM over the concatenated reduction
+    // [t2 | x] . [s3 W3 ; sds Wds] + (b3 + bds) -- the downsample output is never written or re-read (resnet.py:124-144)
+    Layer c3ds;
+    bool fused_ds = false;
 };
 
 // HRNet (backbones/hrnet.py): one HighResolutionModule = per-branch BasicBlocks + the fuse layers
@@ -640,6 +644,24 @@ int hmv_finalize_weights(hmv_handle h) {
             }
             b.has_ds = (b.stride != 1 || inpl != outc);
             if (b.has_ds) L.conv(b.ds, lab + ".downsample", p + ".downsample.0.weight", "", p + ".downsample.1", outc, inpl, 1, 1, 0, h16);
+            static const bool no_fuse = getenv("HMV_NO_DSFUSE") != nullptr;   // development knob (A/B runs)
+            if (b.has_ds && h->paper && !L.split && !no_fuse) {
+                const int CHK = h16 ? 64 : 32;
+                const HostTensor *w3 = L.get(p + ".conv3.weight", {outc, planes, 1, 1}), *wd = L.get(p + ".downsample.0.weight", {outc, inpl, 1, 1});
+                std::vector<double> s3, b3, sd_, bd_;
+                if (w3 && wd && planes % CHK == 0 && inpl % CHK == 0 && L.bn_fold(p + ".bn3", outc, s3, b3) &&
+                    L.bn_fold(p + ".downsample.1", outc, sd_, bd_)) {
+                    const float *a3 = w3->data.data(), *ad = wd->data.data();
+                    std::vector<double> shift(outc);
+                    for (int o = 0; o < outc; ++o) shift[o] = b3[o] + bd_[o];
+                    auto wt = [=, &s3, &sd_](int o, int k) -> double {
+                        return k < planes ? (double)a3[(size_t)o * planes + k] * s3[o] : (double)ad[(size_t)o * inpl + (k - planes)] * sd_[o];
+                    };
+                    L.finish(b.c3ds, lab + ".conv3+downsample", planes + inpl, outc, 1, 1, planes + inpl, wt, nullptr, &shift, nullptr, h16);
+                    b.c3ds.Kreal = planes + inpl;
+                    b.fused_ds = true;
+                }
+            }
             inpl = outc;
             h->blocks[li].push_back(b);
         }
@@ -946,12 +968,27 @@ struct Runner {
     }
 
     // One conv / GEMM launch.  in: NHWC [N][H][W][L.Cin] ; returns output dims through Ho/Wo.
+    // second A source of the next conv() call (conv3 + downsample as one GEMM); consumed by that call
+    struct Dual { const float *in2 = nullptr; int ksplit = 0, H2 = 0, W2 = 0, lda2 = 0, stride2 = 1; } dual;
+
+    // Bottleneck conv3 + BN3 + downsample conv + BN + ReLU in one launch: out = relu([t2 | x(strided)] . Wcat + b)
+    void conv_dual(const Layer &L, const float *t2, int planes, const float *x, int inpl, int N, int Hx, int Wx, int stride, float *out,
+                   int ldc, int Ho, int Wo, bool out_f16) {
+        dual.in2 = x; dual.ksplit = planes; dual.H2 = Hx; dual.W2 = Wx; dual.lda2 = inpl; dual.stride2 = stride;
+        conv(L, t2, N, Ho, Wo, 1, 0, 0, out, ldc, nullptr, 0, ACT_RELU, Ho, Wo, 0, 0, 0, 0, 0, out_f16);
+        dual = Dual();
+    }
+
     void conv(const Layer &L, const float *in, int N, int H, int W, int stride, int pad_h, int pad_w, float *out, int ldc,
               const float *res, int ldr, int act, int Ho, int Wo, int rg_out = 0, int rg_in = 0, int scatter = 0, int ooy = 0,
               int oox = 0, bool out_f16 = false, int up = 0, bool fill = false) {
         if (dry || rc != HMV_OK) return;
         ConvParams p{};
         p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res; p.out = out;
+        if (dual.in2) {
+            p.in2 = dual.in2; p.ksplit = dual.ksplit; p.H2 = dual.H2; p.W2 = dual.W2; p.lda2 = dual.lda2; p.stride2 = dual.stride2;
+            p.lda = dual.ksplit;   // the first source's pixel stride is its own channel count, not the concatenated one
+        }
         p.in_f16 = L.f16; p.out_f16 = out_f16; p.res_f16 = L.f16 && res != nullptr;   // a residual always has the layer's dtype
         p.N = N; p.H = H; p.W = W; p.Cin = L.Cin;
         p.Ho = Ho; p.Wo = Wo; p.Cout = L.Cout;
@@ -996,6 +1033,9 @@ struct Runner {
             const double in_px = (pointwise && stride > 1) ? (double)p.M : (double)N * H * W;
             pr->bytes = in_px * cin_real * eb_in + (double)L.Cout * kreal * eb_in + (double)p.M * cout_real * eb_out +
                         (res ? (double)p.M * cout_real * eb_in : 0.0);
+            if (dual.in2)   // [t2 | x]: t2 at every output pixel, x at the pixels the stride keeps
+                pr->bytes = ((double)p.M * dual.ksplit + (double)p.M * (kreal - dual.ksplit)) * eb_in + (double)L.Cout * kreal * eb_in +
+                            (double)p.M * cout_real * eb_out;
             check(hipEventRecord(pr->e0, s), "hipEventRecord");
         }
         const char *kname = nullptr;
@@ -1213,13 +1253,18 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                 R.release(t1);
                 const float *res = cur;
                 float *dsb = nullptr;
-                if (b.has_ds) {
-                    dsb = R.alloc(ACT((size_t)N * ho * wo * outc));
-                    R.conv(b.ds, cur, N, hh, ww, b.stride, 0, 0, dsb, outc, nullptr, 0, ACT_NONE, ho, wo, 0, 0, 0, 0, 0, h16);
-                    res = dsb;
+                if (b.fused_ds) {   // conv3 and the downsample branch as one GEMM over [t2 | x]
+                    y = R.alloc(ACT((size_t)N * ho * wo * outc));
+                    R.conv_dual(b.c3ds, t2, planes, cur, C, N, hh, ww, b.stride, y, outc, ho, wo, h16);
+                } else {
+                    if (b.has_ds) {
+                        dsb = R.alloc(ACT((size_t)N * ho * wo * outc));
+                        R.conv(b.ds, cur, N, hh, ww, b.stride, 0, 0, dsb, outc, nullptr, 0, ACT_NONE, ho, wo, 0, 0, 0, 0, 0, h16);
+                        res = dsb;
+                    }
+                    y = R.alloc(ACT((size_t)N * ho * wo * outc));
+                    R.conv(b.c3, t2, N, ho, wo, 1, 0, 0, y, outc, res, outc, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, h16);
                 }
-                y = R.alloc(ACT((size_t)N * ho * wo * outc));
-                R.conv(b.c3, t2, N, ho, wo, 1, 0, 0, y, outc, res, outc, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, h16);
                 R.release(t2);
                 R.release(dsb);
             } else {

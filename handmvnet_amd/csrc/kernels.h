@@ -47,6 +47,11 @@ struct ConvParams {
     float acc_scale;    //   the epilogue multiplies the accumulator by 2^-acc_shift (filled in by launch_conv)
     int out_split;      // write (hi, lo) pairs (plane stride ldc / 2) instead of one fp16 value
     int rd_cout;        // row-decomposed 3x3 (narrow Cout): the real channel count; Cout is then 3 * rd_cout, R = 3, S = 1
+    // second A source of a plain 1x1 conv (Bottleneck conv3 and its block's downsample conv as ONE GEMM over the concatenated
+    // reduction [t2 | x] . [W3 ; Wds], resnet.py:124-144): reduction indices >= ksplit read `in2`, an NHWC tensor
+    // [N][H2][W2][lda2] sampled at pixel (ho * stride2, wo * stride2); indices < ksplit read `in` at pixel (ho, wo)
+    const void *in2;
+    int ksplit, H2, W2, lda2, stride2;
     int lda;            // input pixel stride in floats (0 = Cin)
     int ldw;            // weight row stride in floats (0 = Kpad)
     int burst;          // residual tile by one LDS-DMA burst per wave after the main loop (filled in by launch_conv)

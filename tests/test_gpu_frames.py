@@ -81,7 +81,7 @@ def test_forward_frames_equals_forward_on_prepared_batch(name, mode):
     # floor apart (tests/golden/fp16_noise.json, measured on the reference itself; see test_gpu_parity.py)
     tol = fp16_bounds(name)["joints_cam"] if half else 1e-4
     assert rel_l2(fused["joints_cam"].cpu().numpy(), two_step["joints_cam"].cpu().numpy()) < tol
-    assert np.abs(fused["joints_crop_img"].cpu().numpy() - two_step["joints_crop_img"].cpu().numpy()).max() < (0.5 if half else 0.02)
+    assert np.abs(fused["joints_crop_img"].cpu().numpy() - two_step["joints_crop_img"].cpu().numpy()).max() < (1.0 if half else 0.02)   # image px; 1.0 = 1/8 heat-map px, the fp16 noise floor on soft coordinates
     assert rel_l2(fused["heatmap"].cpu().numpy(), two_step["heatmap"].cpu().numpy()) < (5e-3 if half else 1e-4)
 
 

@@ -202,14 +202,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
     }
 
     // ---- XCD-aware tile assignment (bijective for any grid size)
-    int mt, nt;
+    int mt, nt, kslice_id = 0;
     {
         const int nblk = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, r = nblk & 7;
-        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        if (p.ksl > 1) {   // split-K: the slices of one output tile are consecutive blocks (they share the A rows' neighbourhood in L2)
+            kslice_id = lid % p.ksl;
+            lid /= p.ksl;
+        }
         mt = lid / p.ntiles;
         nt = lid - mt * p.ntiles;
     }
+    const size_t koffs = (size_t)kslice_id * p.kslice;                          // this block's first reduction index
+    char *outv = static_cast<char *>(p.out) + (size_t)kslice_id * p.out_slice * sizeof(float);
 
     // ---- DMA roles: thread -> (row lrow of each RPS-row pass, physical chunk tid&7); it fetches the
     // LOGICAL chunk kqs so that the lane-linear LDS image ends up XOR-swizzled.
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
         const int mm = ok ? m : 0;
         const int n = mm / HoWo, rem = mm - n * HoWo;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        const T *base = reinterpret_cast<const T *>(p.in) + (size_t)n * p.H * p.W * p.lda;
+        const T *base = reinterpret_cast<const T *>(p.in) + koffs + (size_t)n * p.H * p.W * p.lda;
         hi0[i] = ok ? ho * p.stride - p.pad_h : -(1 << 28);   // out-of-range rows fail every bounds test
         wi0[i] = wo * p.stride - p.pad_w;
         if (MODE == MODE_1X1) {
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
     const T *wptr[BP];
 #pragma unroll
     for (int i = 0; i < BP; ++i)
-        wptr[i] = reinterpret_cast<const T *>(p.wgt) + (size_t)(nt * BN + i * RPS + lrow) * p.ldw + EPC * kqs;
+        wptr[i] = reinterpret_cast<const T *>(p.wgt) + koffs + (size_t)(nt * BN + i * RPS + lrow) * p.ldw + EPC * kqs;
 
     f32x16 acc[TM][TN];
     // 16-bit result rows (fp16 / (hi, lo) pairs): decides the channel order of the transposed-output accumulators (below)
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
         tnr = __builtin_amdgcn_readfirstlane(tnr < 0 ? 0 : (tnr > TN ? TN : tnr));
     }
     int cr = 0, cs = 0, cc = 0, cdelta = 0, ck = 0;   // load cursor (wave-uniform)
-    const int nk = p.Kpad / KB;
+    const int nk = (p.ksl > 1 ? p.kslice : p.Kpad) / KB;
 
     // issue the DMA of the cursor tile into LDS buffer `buf`, then advance the cursor
 #define HMV_DMA(buf)                                                                                        \
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                         const int g = c0 + i, a = g / TN, b = g % TN, m = mrow0 + 32 * a;
                         // pieces of block i landed when at most the (CB - 1 - i) * PC younger DMAs + the i * PC stores since are out
                         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((CB - 1) * PC) : "memory");
-                        float *orow = reinterpret_cast<float *>(p.out) + (size_t)m * p.ldc;
+                        float *orow = reinterpret_cast<float *>(outv) + (size_t)m * p.ldc;
 #pragma unroll
                         for (int q = 0; q < PC; ++q) {
                             const int col = nb0 + 32 * b + 8 * q + 4 * kh;
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                         for (int i = 0; i < CB; ++i) {
                             const int g = c0 + i, a = g / TN, b = g % TN, m = mrow0 + 32 * a;
                             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((CB - 1) * PC) : "memory");   // PC stores per block follow PC DMAs
-                            _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc;
+                            _Float16 *orow = reinterpret_cast<_Float16 *>(outv) + (size_t)m * p.ldc;
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
                                 const int col = nb0 + 32 * b + 16 * j + 8 * kh;
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                 if (g >= 0) {
                     const int a = g / TN, b = g % TN;
                     const int m = mrow0 + 32 * a;
-                    float *orow = reinterpret_cast<float *>(p.out) + (size_t)m * p.ldc;
+                    float *orow = reinterpret_cast<float *>(outv) + (size_t)m * p.ldc;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int col = nb0 + 32 * b + 8 * q + 4 * kh;
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                     if (g >= 0) {
                         const int a = g / TN, b = g % TN;
                         const int m = mrow0 + 32 * a;
-                        _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc;
+                        _Float16 *orow = reinterpret_cast<_Float16 *>(outv) + (size_t)m * p.ldc;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const int col = nb0 + 32 * b + 16 * j + 8 * kh;
@@ -825,10 +831,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], lo);
                 if (p.out_f16)
-                    *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc + 4 * c4) =
+                    *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(outv) + (size_t)m * p.ldc + 4 * c4) =
                         f16x4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
                 else
-                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out) + (size_t)m * p.ldc + 4 * c4) = t;
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(outv) + (size_t)m * p.ldc + 4 * c4) = t;
             }
         } else if (vec) {
             if constexpr (!F16) {   // the fp32 kernels keep their hand-tuned 4-wide drain (any restructuring here costs ~3 %)
@@ -897,14 +903,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                                     hv[j] = (_Float16)c;
                                     lv[j] = (_Float16)(c - (float)hv[j]);
                                 }
-                                _Float16 *op = reinterpret_cast<_Float16 *>(p.out) + orow[u] * p.ldc + col;
+                                _Float16 *op = reinterpret_cast<_Float16 *>(outv) + orow[u] * p.ldc + col;
                                 *reinterpret_cast<f16x4 *>(op) = hv;
                                 *reinterpret_cast<f16x4 *>(op + (p.ldc >> 1)) = lv;
                             } else if (p.out_f16)
-                                *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + orow[u] * p.ldc + col) =
+                                *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(outv) + orow[u] * p.ldc + col) =
                                     f16x4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
                             else
-                                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out) + orow[u] * p.ldc + col) = t;
+                                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(outv) + orow[u] * p.ldc + col) = t;
                         }
                     }
                 }
@@ -997,7 +1003,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                                 hv[j] = (_Float16)c;
                                 lv[j] = (_Float16)(c - (float)hv[j]);
                             }
-                            _Float16 *op = reinterpret_cast<_Float16 *>(p.out) + orow[u] * p.ldc + col;
+                            _Float16 *op = reinterpret_cast<_Float16 *>(outv) + orow[u] * p.ldc + col;
                             if constexpr (W == 8) {
                                 *reinterpret_cast<f16x8 *>(op) = f16x8{hv[0], hv[1], hv[2], hv[3], hv[4], hv[5], hv[6], hv[7]};
                                 *reinterpret_cast<f16x8 *>(op + (p.ldc >> 1)) = f16x8{lv[0], lv[1], lv[2], lv[3], lv[4], lv[5], lv[6], lv[7]};
@@ -1006,7 +1012,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                                 *reinterpret_cast<f16x4 *>(op + (p.ldc >> 1)) = f16x4{lv[0], lv[1], lv[2], lv[3]};
                             }
                         } else if (p.out_f16) {
-                            _Float16 *op = reinterpret_cast<_Float16 *>(p.out) + orow[u] * p.ldc + col;
+                            _Float16 *op = reinterpret_cast<_Float16 *>(outv) + orow[u] * p.ldc + col;
                             if constexpr (W == 8)
                                 *reinterpret_cast<f16x8 *>(op) = f16x8{(_Float16)t[0][0], (_Float16)t[0][1], (_Float16)t[0][2], (_Float16)t[0][3],
                                                                        (_Float16)t[W4 - 1][0], (_Float16)t[W4 - 1][1], (_Float16)t[W4 - 1][2], (_Float16)t[W4 - 1][3]};
@@ -1015,7 +1021,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                         } else {
 #pragma unroll
                             for (int q = 0; q < W4; ++q)
-                                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out) + orow[u] * p.ldc + col + 4 * q) = t[q];
+                                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(outv) + orow[u] * p.ldc + col + 4 * q) = t[q];
                         }
                     }
                 }
@@ -1044,8 +1050,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                 if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
                 else if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
                 else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-                if (p.out_f16) reinterpret_cast<_Float16 *>(p.out)[orow * p.ldc + col] = (_Float16)v;
-                else reinterpret_cast<float *>(p.out)[orow * p.ldc + col] = v;
+                if (p.out_f16) reinterpret_cast<_Float16 *>(outv)[orow * p.ldc + col] = (_Float16)v;
+                else reinterpret_cast<float *>(outv)[orow * p.ldc + col] = v;
             }
         }
     }
@@ -1150,7 +1156,7 @@ static hipError_t launch_one(ConvParams p, hipStream_t s) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.Cout + BN - 1) / BN;
     if (p.mtiles * p.ntiles < 4 * p.stagger_blocks) p.stagger = 0;   // too few rounds for a start-up offset to pay
-    hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(64 * WGM * WGN), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles * (p.ksl > 1 ? p.ksl : 1)), dim3(64 * WGM * WGN), lds, s, p);
     return hipGetLastError();
 }
 
@@ -1201,6 +1207,9 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         (((p.out_split ? p.ldc >> 1 : p.ldc) & 7) || (p.res && ((p.res_split ? p.ldr >> 1 : p.ldr) & 7))))
         generic = true;
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
+    if (p.ksl > 1 && (!one || p.in_f16 || p.in2 || p.up || p.res || p.act != ACT_NONE || p.kslice <= 0 || p.kslice % 32 != 0 ||
+                      p.ksl * p.kslice != p.Kpad || p.Cin % 32 != 0))
+        return hipErrorInvalidValue;   // split-K: plain fp32 GEMM slices, epilogue left to the reduction kernel
     if (p.in2 && (!one || p.stride != 1 || p.up || p.cwrap || p.x3_plane || p.rd_cout || p.ksplit <= 0 || p.ksplit >= p.K ||
                   p.ksplit % (p.in_f16 ? 64 : 32) != 0 || p.Cin % (p.in_f16 ? 64 : 32) != 0))
         return hipErrorInvalidValue;   // the second source exists in the chunked 1x1 mode only

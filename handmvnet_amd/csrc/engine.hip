@@ -174,6 +174,7 @@ struct hmv_engine {
     float *cheb_t = nullptr;
     Layer fc1, fc2;
     float *pe = nullptr;
+    float *zero_bias = nullptr;   // 4096 zeros: bias of split-K slices
 
     char *arena = nullptr;
     size_t arena_bytes = 0;
@@ -848,6 +849,7 @@ int hmv_finalize_weights(hmv_handle h) {
         L.linear(h->fc1, "decoder.fc1", "joints_decoder.joints_fc1.weight", "joints_decoder.joints_fc1.bias", 64, d);
         L.linear(h->fc2, "decoder.fc2", "joints_decoder.joints_fc2.weight", "joints_decoder.joints_fc2.bias", 3, 64);
     }
+    h->zero_bias = L.upload(std::vector<float>(4096, 0.f));
     if (L.rc != HMV_OK) return L.rc;
     HIPCHK(h, hipDeviceSynchronize());
     h->finalized = true;
@@ -968,6 +970,7 @@ struct Runner {
     }
 
     // One conv / GEMM launch.  in: NHWC [N][H][W][L.Cin] ; returns output dims through Ho/Wo.
+    int ksplit = 1;   // split-K slices of the next conv() call (gemm() below)
     // second A source of the next conv() call (conv3 + downsample as one GEMM); consumed by that call
     struct Dual { const float *in2 = nullptr; int ksplit = 0, H2 = 0, W2 = 0, lda2 = 0, stride2 = 1; } dual;
 
@@ -985,6 +988,7 @@ struct Runner {
         if (dry || rc != HMV_OK) return;
         ConvParams p{};
         p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res; p.out = out;
+        if (ksplit > 1) { p.ksl = ksplit; p.kslice = L.Kpad / ksplit; p.out_slice = (size_t)N * Ho * Wo * ldc; }
         if (dual.in2) {
             p.in2 = dual.in2; p.ksplit = dual.ksplit; p.H2 = dual.H2; p.W2 = dual.W2; p.lda2 = dual.lda2; p.stride2 = dual.stride2;
             p.lda = dual.ksplit;   // the first source's pixel stride is its own channel count, not the concatenated one
@@ -1048,7 +1052,27 @@ struct Runner {
 
     void gemm(const Layer &L, const float *a, int rows, float *out, int ldc, const float *res, int ldr, int act, int rg_out = 0,
               int rg_in = 0) {
-        conv(L, a, rows, 1, 1, 1, 0, 0, out, ldc, res, ldr, act, 1, 1, rg_out, rg_in);
+        // split-K (layers.py:224 to_out: K = 1024, and 2048 in the learnable-query blocks): a long reduction over few token rows
+        // tiles into a few dozen workgroups at a small batch.  K is cut into 4 slices that run as 4x the workgroups of ONE
+        // launch; a reduction kernel adds the partial products in slice order and applies bias / residual / activation.
+        // The cut depends on K alone -- never on the batch -- so a sample's result does not depend on what it is batched with
+        // (tests/test_gpu_parity.py::test_full_size_properties).  Same alloc / release sequence in the dry (planning) run.
+        static const bool no_splitk = getenv("HMV_NO_SPLITK") != nullptr;   // development knob (A/B runs)
+        const int S = (!no_splitk && !L.f16 && L.R == 1 && L.S == 1 && !L.plane && L.Kpad >= 1024 && L.Kpad % 128 == 0 && rows > 0) ? 4 : 1;
+        if (S == 1) {
+            conv(L, a, rows, 1, 1, 1, 0, 0, out, ldc, res, ldr, act, 1, 1, rg_out, rg_in);
+            return;
+        }
+        const int lds_ = (L.Cout + 3) / 4 * 4;
+        float *slab = alloc((size_t)S * rows * lds_);
+        Layer Ls = L;
+        Ls.bias = h->zero_bias;
+        ksplit = S;
+        conv(Ls, a, rows, 1, 1, 1, 0, 0, slab, lds_, nullptr, 0, ACT_NONE, 1, 1);
+        ksplit = 1;
+        if (!dry && rc == HMV_OK)
+            check(launch_splitk_reduce(slab, S, rows, lds_, L.Cout, L.bias, res, ldr, rg_out, rg_in, act, out, ldc, s), "splitk_reduce");
+        release(slab);
     }
 };
 

@@ -54,6 +54,10 @@ struct ConvParams {
     int ksplit, H2, W2, lda2, stride2;
     int lda;            // input pixel stride in floats (0 = Cin)
     int ldw;            // weight row stride in floats (0 = Kpad)
+    // split-K (plain fp32 1x1 / GEMM launches): `ksl` slices of `kslice` reduction elements run as ksl x the workgroups; slice s
+    // reads in + s * kslice, wgt + s * kslice and writes its partial product to out + s * out_slice (floats); the caller adds them
+    int ksl, kslice;
+    size_t out_slice;
     int burst;          // residual tile by one LDS-DMA burst per wave after the main loop (filled in by launch_conv)
     int prefetch;       // software L2 prefetch of the residual tile / later activation k-steps (filled in by launch_conv)
     int stagger;        // start-up stagger (filled in by launch_conv): the workgroups of the first dispatch round are split into 4
@@ -118,6 +122,9 @@ hipError_t launch_attention_d256(const float *q, int q_ld, int q_bstride, const 
                                  int Tq, float *out, hipStream_t s);
 // y[r][c] = x[r][c] + pe[r % T][c] for c < d, 0 for d <= c < ldy (PositionalEncoding inside every learnable-query block)
 hipError_t launch_add_pe(const float *x, int ldx, int rows, int T, int d, const float *pe, float *y, int ldy, hipStream_t s);
+// split-K GEMM tail: out[r][c] = act(sum_s slab[s][r][c] + bias[c] + res[r'][c]) for c < N (slices summed in index order)
+hipError_t launch_splitk_reduce(const float *slab, int S, int rows, int lds, int N, const float *bias, const float *res, int ldr,
+                                int rg_out, int rg_in, int act, float *out, int ldc, hipStream_t s);
 // Chebyshev mix: out[b][i][o] = act(sum_k sum_j Tk[k][i][j] * y[b*21+j][k*co + o] + bias[o])
 hipError_t launch_cheb_mix(const float *y, int ldy, int B, int co, const float *tk, const float *bias, int leaky,
                            float *out, int ldo, hipStream_t s);

@@ -673,6 +673,41 @@ hipError_t launch_attention_d256(const float *q, int q_ld, int q_bstride, const 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ split-K reduction
+// The token GEMMs of a small batch (to_out: M = B*V*21 rows, N = d, K = 1024) tile into a few dozen workgroups with a long
+// serial reduction.  The engine cuts K into S slices (S times the workgroups, 1/S the k-steps), each slice writes a plain
+// partial product, and this kernel adds the slices in index order (deterministic) and applies the GEMM's epilogue.
+__global__ void splitk_reduce_kernel(const float *__restrict__ slab, int S, size_t slice, int lds, int N, const float *__restrict__ bias,
+                                     const float *__restrict__ res, int ldr, int rg_out, int rg_in, int act, float *__restrict__ out,
+                                     int ldc, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const size_t r = i / N;
+        const int c = (int)(i - r * N);
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += slab[s * slice + r * lds + c];
+        v += bias[c];
+        if (res) {
+            const size_t rr = rg_out ? (r / rg_out) * rg_in + (r % rg_out) : r;
+            v += res[rr * ldr + c];
+        }
+        if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        else if (act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+        out[r * ldc + c] = v;
+    }
+}
+hipError_t launch_splitk_reduce(const float *slab, int S, int rows, int lds, int N, const float *bias, const float *res, int ldr,
+                                int rg_out, int rg_in, int act, float *out, int ldc, hipStream_t s) {
+    const size_t total = (size_t)rows * N;
+    if (!total) return hipSuccess;
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, slab, S, (size_t)rows * lds, lds, N, bias, res, ldr, rg_out,
+                       rg_in, act, out, ldc, total);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ ChebConv mix
 // layers.py:387-403: sum_k T_k (X W_k) + b, the X W_k products come from one GEMM with N = 3*co.
 __global__ void cheb_mix_kernel(const float *__restrict__ y, int ldy, int co, const float *__restrict__ tk,

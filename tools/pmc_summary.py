@@ -25,16 +25,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def family(name: str) -> str:
     """rocprofv3 symbol -> the kernel family name bench.py / the engine use (one symbol per family)."""
-    m = re.match(r"(?:void )?(?:hmv::)?conv_igemm<(float|_Float16), (\d+), (\d+), \d+, \d+, (\d), (?:false|true), (\d+)(?:, (false|true))?(?:, (false|true))?>", name)
+    m = re.match(r"(?:void )?(?:hmv::)?conv_igemm<(float|_Float16), (\d+), (\d+), \d+, \d+, (\d), (?:false|true), (\d+)(?:, (false|true))?(?:, (false|true))?(?:, (?:false|true))?>", name)
     if m:
         t = "f32" if m.group(1) == "float" else "f16"
         k16 = ",k16" if (t == "f32" and m.group(5) == "16") else ""
         skip = ",rowsum" if m.group(7) == "true" else (",skipN" if m.group(6) == "true" else "")
         return f"conv_igemm_{t}<{m.group(2)}x{m.group(3)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense"}[m.group(4)] + skip + ">"
     # rocprofv3 leaves the _Float16 instantiations mangled (DF16_): conv_igemm<_Float16, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD>
-    m = re.match(r"_ZN3hmv10conv_igemmIDF16_Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)ELb[01]ELi(\d+)E", name)
+    m = re.match(r"_ZN3hmv10conv_igemmIDF16_Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)ELb[01]ELi(\d+)ELb[01]ELb([01])E", name)
     if m:
-        return f"conv_igemm_f16<{m.group(1)}x{m.group(2)}," + {"0": "taps", "1": "1x1", "2": "dense"}[m.group(3)] + ">"
+        k16 = ",k16" if m.group(4) == "32" else ""
+        return f"conv_igemm_f16<{m.group(1)}x{m.group(2)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense"}[m.group(3)] + \
+            (",rowsum" if m.group(5) == "1" else "") + ">"
     return re.sub(r"\(.*", "", name).replace("void ", "").replace("hmv::", "")
 
 
@@ -82,10 +84,21 @@ def main():
     out = {"tag": tag, "sq": dict(sorted(sq.items(), key=lambda kv: -kv[1]["total_ms"])), "traffic": traffic,
            "corrections": "FETCH_SIZE x2 (gfx950 wide loads), KiB -> bytes; WRITE_SIZE exact"}
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
-    if "--no-traffic-file" not in sys.argv:   # pmc_traffic.json belongs to the default (fp32) bench run
-        json.dump({"source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)",
-                   "kernels": {f: t["hbm_bytes_per_launch"] for f, t in traffic.items()}},
-                  open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    if "--no-traffic-file" not in sys.argv:   # profiles/pmc_traffic.json: one entry per arithmetic mode of bench.py (--dtype)
+        dtype = "f32"
+        for a in sys.argv:
+            if a.startswith("--dtype="):
+                dtype = a.split("=", 1)[1]
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        try:
+            allm = json.load(open(path))
+            if "kernels" in allm:      # round-1 layout: one unnamed (fp32) entry
+                allm = {"f32": dict(allm, dtype="f32")}
+        except (OSError, ValueError):
+            allm = {}
+        allm[dtype] = {"source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --dtype {dtype})",
+                       "dtype": dtype, "kernels": {f: t["hbm_bytes_per_launch"] for f, t in traffic.items()}}
+        json.dump(allm, open(path, "w"), indent=1)
     for f, v in list(out["sq"].items())[:6]:
         print(f, v, {k: round(x / 1e6, 1) for k, x in traffic.get(f, {}).items() if k.endswith("launch")})
 

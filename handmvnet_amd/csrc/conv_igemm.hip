@@ -144,7 +144,7 @@ constexpr int lds_floats(int BM, int BN, int WGM, int KB, bool full = false, boo
 #define HMV_OCC2 1
 #endif
 constexpr int min_waves(int BM, int BN, int NT, bool f16, bool generic, bool rd, int KB) {
-    return (HMV_OCC2 && f16 && KB == 32 && !generic && !rd && NT == 512 && BM * BN == 256 * 128) ? 4 : (NT == 512 ? 2 : 1);
+    return (HMV_OCC2 && KB == (f16 ? 32 : 16) && !generic && !rd && NT == 512 && BM * BN == 256 * 128) ? 4 : (NT == 512 ? 2 : 1);
 }
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false, bool X3 = false>
 __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, sizeof(T) == 2, GENERIC, RD, KB)) void conv_igemm(const ConvParams p) {
@@ -1078,7 +1078,7 @@ int conv_tile_bn(ConvTile t) {
 
 // Family name = one rocprofv3 symbol: conv_igemm<T, BM, BN, WGM, WGN, MODE, false, KB>
 static const char *kTileShape[TILE_COUNT] = {"128x32", "128x64", "128x128", "256x128", "128x256", "256x256", "128x128,k16",
-                                              "128x256,k16", "256x128,k16", "64x64"};
+                                              "128x256,k16", "256x128,k16", "64x64", "256x128,k16,w8"};
 static const char *tile_name(const char *dtype, ConvTile t, int mode, bool partn = false, bool rd = false) {
     static char names[2][TILE_COUNT][3][3][56];
     if (t < 0 || t >= TILE_COUNT || mode < 0 || mode > 2) return "conv_igemm<?>";
@@ -1110,7 +1110,7 @@ bool conv_partial_n(ConvTile t, int Cout) {
     return (Cout + bn - 1) / bn * bn - Cout >= 32;
 }
 
-ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool /*has_res*/) {
+ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
     static int forced = -2;   // development knob: HMV_FORCE_TILE=<ConvTile> for layers with Cout > 64
     if (forced == -2) { const char *e = getenv("HMV_FORCE_TILE"); forced = e ? atoi(e) : -1; }
     if (Cout > 64 && forced >= 0 && forced < TILE_COUNT) return (ConvTile)forced;
@@ -1121,6 +1121,13 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool /*has_res*/) {
     // fp32 only: with 16-byte vectors on both sides of the fp16 epilogue the big tile wins there too (forced-tile
     // A/B runs of bench.py --dtype f16 / f32x3 --per-layer)
     if (!f16 && Cout >= 256 && K <= 128 && M >= 65536) return TILE_128x128_K16;
+    // residual-bearing expanding convs with a medium reduction (layer3 conv3: 256 -> 1024 + residual): a 256x256 workgroup owns
+    // its CU, so its 20 us drain overlaps nothing (75 us main loop: 100 TF).  Two 8-wave 256x128 workgroups per CU (k-step 16,
+    // 48 KB of tile buffers, <= 128 registers) alternate: one drains while the other computes -- 1.44 -> 1.30 ms per launch
+    // although each main loop is less efficient (tools/stagger_probe.py, profiles/r02_probe_w8.txt)
+    static const bool no_w8 = getenv("HMV_NO_W8") != nullptr;   // development knob (A/B runs)
+    if (!no_w8 && !f16 && has_res && K <= 256 && Cout >= 512 && (long long)((M + 255) / 256) * ((Cout + 127) / 128) >= 2048)
+        return TILE_256x128_K16W8;
     // channel counts that are not multiples of 128 (HRNet-w40: 160, 320), measured with tools/hr_sweep.py: one 256-wide
     // N-tile with its all-padding blocks skipped beats two 128-wide tiles whose second one is mostly DMA latency;
     // 64-wide tiles beat 128-wide ones when the last 128-wide tile would be at most half real.
@@ -1213,7 +1220,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     if (p.in2 && (!one || p.stride != 1 || p.up || p.cwrap || p.x3_plane || p.rd_cout || p.ksplit <= 0 || p.ksplit >= p.K ||
                   p.ksplit % (p.in_f16 ? 64 : 32) != 0 || p.Cin % (p.in_f16 ? 64 : 32) != 0))
         return hipErrorInvalidValue;   // the second source exists in the chunked 1x1 mode only
-    if (generic && (tile == TILE_256x128 || tile == TILE_128x256 || tile == TILE_256x256 || tile == TILE_128x128_K16 ||
+    if (generic && (tile == TILE_256x128 || tile == TILE_128x256 || tile == TILE_256x256 || tile == TILE_128x128_K16 || tile == TILE_256x128_K16W8 ||
                     tile == TILE_128x256_K16 || tile == TILE_256x128_K16))
         tile = TILE_128x128;   // the rarely used epilogue paths exist only for the 4-wave tiles
     const int ch = p.in_f16 ? 64 : 32, epc = p.in_f16 ? 8 : 4;
@@ -1318,6 +1325,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         case TILE_128x256_K16: return launch_plain<float, 128, 256, 2, 2, 16>(p, one, s);
         case TILE_256x128_K16: return launch_plain<float, 256, 128, 2, 2, 16>(p, one, s);
         case TILE_64x64: return launch_modes<float, 64, 64, 2, 2, 32>(p, one, generic, s);
+        case TILE_256x128_K16W8: return launch_plain<float, 256, 128, 4, 2, 16>(p, one, s);
         default: return hipErrorInvalidValue;
     }
 }

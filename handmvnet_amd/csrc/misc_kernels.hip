@@ -487,12 +487,17 @@ hipError_t launch_layernorm(const float *x, int ldx, int rows, int d, const floa
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int ATT_LDK = 132;   // K chunk row stride (floats): conflict-free ds_read_b128 of the B operand
 constexpr int ATT_LDP = 36;    // P scratch row stride
+constexpr int ATT_WAVES = 8;   // 8 waves = 8 query blocks (256 query rows) per pass: T = 168 (8 views) is ONE pass
+constexpr int ATT_LDS_FLOATS = 32 * ATT_LDK + 32 * 128 + ATT_WAVES * 32 * ATT_LDP;
 
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__restrict__ qkv, int T, int Tq, int koff, int Tk,
-                                                             float *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float sK[32 * ATT_LDK];
-    __shared__ __attribute__((aligned(16))) float sV[32 * 128];
-    __shared__ __attribute__((aligned(16))) float sP[4][32 * ATT_LDP];
+// Round 2: 8 waves per (sample, head) instead of 4: the 6 query blocks of an 8-view sample no longer need a second,
+// half-empty pass that re-stages every K / V chunk.  The arithmetic of a query block is unchanged (bit-identical results).
+__global__ __launch_bounds__(64 * ATT_WAVES) void attention_mfma_kernel(const float *__restrict__ qkv, int T, int Tq, int koff, int Tk,
+                                                                        float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float att_smem[];
+    float *sK = att_smem;                       // [32][ATT_LDK]
+    float *sV = sK + 32 * ATT_LDK;              // [32][128]
+    float *sPall = sV + 32 * 128;               // [ATT_WAVES][32][ATT_LDP]
     const int b = blockIdx.x >> 3, h = blockIdx.x & 7;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -501,10 +506,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
     const float *qb = base + h * 128, *kb = base + (size_t)koff * ld + 1024 + h * 128, *vb = base + (size_t)koff * ld + 2048 + h * 128;
     const int nqb = (Tq + 31) >> 5, nkc = (Tk + 31) >> 5;
     const float scale = 0.08838834764831845f;  // 128 ** -0.5
-    float *pw = sP[wave];
+    float *pw = sPall + wave * 32 * ATT_LDP;
+    constexpr int NST = 1024 / (64 * ATT_WAVES);   // 16-byte vectors of K (and as many of V) each thread stages per chunk
 
-    for (int pass = 0; pass * 4 < nqb; ++pass) {
-        const int qblk = pass * 4 + wave;
+    for (int pass = 0; pass * ATT_WAVES < nqb; ++pass) {
+        const int qblk = pass * ATT_WAVES + wave;
         const bool active = qblk < nqb;              // wave-uniform
         const int qrow = qblk * 32 + l31;
         // Q block as the A operand: lane (row l31, k-half kh) holds Q[row][8u + 4kh + e]
@@ -525,10 +531,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
 
         for (int kc = 0; kc < nkc; ++kc) {
             __syncthreads();   // previous chunk fully consumed
-            // stage K and V chunk (32 keys x 128): 1024 + 1024 16-byte vectors, 8 per thread; keys >= Tk are zeros
+            // stage K and V chunk (32 keys x 128 dims each = 1024 + 1024 16-byte vectors); keys >= Tk are zeros
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int idx = it * 256 + tid, j = idx >> 5, c4 = idx & 31, key = kc * 32 + j;
+            for (int it = 0; it < NST; ++it) {
+                const int idx = it * 64 * ATT_WAVES + tid, j = idx >> 5, c4 = idx & 31, key = kc * 32 + j;
                 f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
                 if (key < Tk) {
                     kv = *reinterpret_cast<const f32x4 *>(kb + (size_t)key * ld + 4 * c4);
@@ -551,7 +557,6 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
             }
             // ---- online softmax.  Register e holds row (e&3) + 8*(e>>2) + 4*kh, column = this lane's key
             const bool kvalid = kc * 32 + l31 < Tk;
-            float alpha[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float sv = kvalid ? sacc[e] * scale : -INFINITY;
@@ -559,16 +564,14 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
 #pragma unroll
                 for (int ofs = 16; ofs > 0; ofs >>= 1) mx = fmaxf(mx, __shfl_xor(mx, ofs, 64));   // stays inside the 32-lane half
                 const float m_new = fmaxf(m_run[e], mx);                                        // finite: chunk has >= 1 valid key
-                alpha[e] = expf(m_run[e] - m_new);                                                 // exp(-inf) = 0 on the first chunk
+                const float alpha = expf(m_run[e] - m_new);                                        // exp(-inf) = 0 on the first chunk
                 const float pe = kvalid ? expf(sv - m_new) : 0.f;
-                l_run[e] = l_run[e] * alpha[e] + pe;
+                l_run[e] = l_run[e] * alpha + pe;
                 m_run[e] = m_new;
                 pw[((e & 3) + 8 * (e >> 2) + 4 * kh) * ATT_LDP + l31] = pe;                     // P[row][key]
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c][e] *= alpha;
             }
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[c][e] *= alpha[e];
             __builtin_amdgcn_wave_barrier();
             // ---- O += P V: A = P (query row on the lane), B = V chunk (channel on the lane)
 #pragma unroll
@@ -602,7 +605,16 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
 }
 hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s) {
     if (Tk <= 0 || Tq <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attention_mfma_kernel, dim3(B * 8), dim3(256), 0, s, qkv, T, Tq, koff, Tk, out);
+    static bool configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    const int lds = ATT_LDS_FLOATS * (int)sizeof(float);
+    if (!configured[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        configured[dev] = true;
+    }
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3(B * 8), dim3(64 * ATT_WAVES), lds, s, qkv, T, Tq, koff, Tk, out);
     return hipGetLastError();
 }
 

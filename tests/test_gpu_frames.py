@@ -52,7 +52,8 @@ def test_prepare_frames_matches_oracle_on_camera_sized_frames():
 
 
 @pytest.mark.parametrize("name,mode", [("tiny_r18", "f32"), ("cfg1_r50_v4_128", "f32"), ("hr40_tiny", "f32"), ("tiny_r50", "f16"),
-                                       ("cfg1_r50_v4_128", "f32x3"), ("hr40_tiny", "f32x3")])
+                                       ("cfg1_r50_v4_128", "f32x3"), ("hr40_tiny", "f32x3"),
+                                       ("r50_200", "f32"), ("r18_100", "f32"), ("r50_lq", "f32")])   # odd frame sizes, learnable-query fusion
 def test_forward_frames_equals_forward_on_prepared_batch(name, mode):
     from handmvnet_amd import HandMvNet
     cfg, (tp, mp, dp), sd, (x, bbox, intr), fx = load_case(name)

@@ -33,23 +33,25 @@ def _call_into(m, x, bbox, cam, outs):
     m._last_key = (x.shape[-2], x.shape[-1], 0, b, 0)
 
 
-def _outs(x):
+def _outs(x, m=None):
     b, v, _, hh, ww = x.shape
+    from handmvnet_amd.spec import heatmap_size_of
+    hs = heatmap_size_of(m.cfg, hh, ww) if m is not None else (hh // 8, ww // 8)
     return [torch.zeros(b, v, 21, 2, device=x.device), torch.zeros(b, 21, 3, device=x.device),
-            torch.zeros(b, v, 21, hh // 8, ww // 8, device=x.device)]
+            torch.zeros((b, v, 21) + tuple(hs), device=x.device)]
 
 
-@pytest.mark.parametrize("name", ["tiny_r18", "cfg1_r50_v4_128", "hr40_tiny", "r18_single_view"])
+@pytest.mark.parametrize("name", ["tiny_r18", "cfg1_r50_v4_128", "hr40_tiny", "r18_single_view", "r50_lq", "r18_100"])
 def test_graph_replay_is_bit_identical_to_eager(name):
     m, x, bbox, cam = _model(name)
     bb = bbox.reshape(-1, 4).contiguous().float()
     cam = {"intrinsic": cam["intrinsic"].reshape(-1, 4).contiguous().float()}
     m.use_graphs(False)
-    eager = _outs(x)
+    eager = _outs(x, m)
     _call_into(m, x, bb, cam, eager)
     torch.cuda.synchronize()
     m.use_graphs(True)
-    outs = _outs(x)
+    outs = _outs(x, m)
     for i in range(4):                      # eager, capture + first launch, replay, replay
         for o in outs:
             o.fill_(float("nan"))

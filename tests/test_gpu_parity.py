@@ -380,3 +380,46 @@ def test_split_precision_path_meets_the_fp32_bar(name):
     ref32 = _run(m, x, bbox, intr)
     d = rel_l2(got["feat0"], ref32["feat0"])
     assert 0 < d < 2e-5, d
+
+
+# ---------------------------------------------------------------------------------------------
+# Seeded random configurations against the f64 oracle: backbone x views x frame size (incl. sizes that are not multiples of
+# 32 and H != W) x positional-encoding subset x decoder x fusion kind x fusion depth x batch.  The fixtures pin named
+# configurations; this sweeps the combinations between them.
+# ---------------------------------------------------------------------------------------------
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    bt = ["18", "34", "50_paper"][int(rng.integers(0, 3))]
+    ch = [1024] if bt == "50_paper" else [[256, 128, 64], [256, 128], [256]][int(rng.integers(0, 3))]
+    pos = [p for p in ("pos2d", "crop", "sin") if rng.random() < 0.6]
+    lq = bool(rng.random() < 0.3)
+    spec = dict(bt=bt, ch=ch, V=int(rng.integers(1, 6)), B=int(rng.integers(1, 4)), size=64, pos=pos, gcn=bool(rng.random() < 0.5),
+                wseed=1000 + seed, iseed=2000 + seed, fusion="cross_attn_learnable_query" if lq else "cross_attn",
+                fusion_layers=int([1, 3, 5][int(rng.integers(0, 3))]), freeze_bn=bool(rng.random() < 0.3))
+    hh, ww = [int(v) for v in rng.choice([64, 72, 88, 96, 100, 120], 2)]
+    return spec, hh, ww
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_configurations_match_oracle(seed):
+    from cases import case_params
+    from handmvnet_amd import HandMvNet
+    from handmvnet_amd.spec import config_from_params, heatmap_size_of
+    from handmvnet_amd.synth import normalish, synth_inputs, synth_state_dict
+    from oracle.oracle import Oracle
+    spec, hh, ww = _random_case(seed)
+    tp, mp, dp = case_params(spec)
+    cfg = config_from_params(tp, mp, dp)
+    sd = synth_state_dict(cfg, spec["wseed"])
+    _, bbox, intr = synth_inputs(cfg, spec["B"], spec["iseed"], 64)
+    x = normalish("input.random", spec["iseed"], spec["B"] * spec["V"] * 3 * hh * ww).astype(np.float32).reshape(spec["B"], spec["V"], 3, hh, ww)
+    m = HandMvNet(tp, mp, dp)
+    m.load_state_dict(sd, strict=True)
+    got = _run(m, x, bbox, intr)
+    ref = Oracle(cfg, sd, "f64").forward(x, bbox, intr, stages=True)
+    assert got["heatmap"].shape == ref["heatmap"].shape == (spec["B"], spec["V"], 21) + tuple(heatmap_size_of(cfg, hh, ww))
+    rep = {k: rel_l2(got[k], ref[k]) for k in ("joints_cam", "heatmap", "feat0", "tokens", "fused")}
+    rep["coords"] = float(np.abs(got["coords_hm"] - ref["coords_hm"]).max())
+    print(seed, spec, (hh, ww), rep)
+    assert rep["joints_cam"] <= TOL_CAM and rep["coords"] < 0.05, (spec, hh, ww, rep)
+    assert max(rep["heatmap"], rep["feat0"], rep["tokens"], rep["fused"]) <= TOL_STAGE, (spec, hh, ww, rep)

@@ -440,6 +440,22 @@ struct Loader {
         finish(L, label, round_up(in, 32), out, 1, 1, in, wt, nullptr, nullptr, b ? b->data.data() : nullptr);
     }
 
+    // A bias-free fp32 linear on the fused split kernels (the fp16 / f32x3 modes' qkv projections): token rows arrive as
+    // [hi plane | lo plane] halfs, a k-step is 32 columns as [32 W_hi | 32 W_lo]; fp32-equivalent, 3 fp16 MFMAs per fp32 one
+    template <typename F>
+    void linear_x3(Layer &L, const std::string &label, int plane, int out, int in, F wt) {
+        auto wp = [=](int o, int k) -> float {
+            const int c = (k / 64) * 32 + k % 32;
+            return c < in ? wt(o, c) : 0.f;
+        };
+        std::vector<unsigned char> lo((size_t)2 * plane);
+        for (int k = 0; k < 2 * plane; ++k) lo[k] = (k % 64) >= 32;
+        finish(L, label, 2 * plane, out, 1, 1, 2 * plane, wp, nullptr, nullptr, nullptr, true, &lo);
+        L.Kreal = in;
+        L.plane = plane;
+        L.x3n = true;
+    }
+
     float *vec(const std::string &key, int n) {
         const HostTensor *t = get(key, {n});
         return t ? upload(t->data) : nullptr;
@@ -733,6 +749,9 @@ int hmv_finalize_weights(hmv_handle h) {
     } else {
         h->pe = nullptr;
     }
+    // fp16 / f32x3 modes: the q/k/v projections (the fusion stage's largest GEMMs) run on the fused split fp16 kernels --
+    // fp32-equivalent results at a third of the fp32 MFMA time.  Chosen by dtype alone, never by the batch.
+    const bool x3lin = h16 && !getenv("HMV_NO_X3LIN");
     if (h->lq) {
         // CrossAttentionFusionLearnableQuery: fusion.py:33-49; MultiHeadAttentionLearnableQuery: layers.py:240-301
         for (int l = 0; l < 5; ++l) {
@@ -746,7 +765,8 @@ int hmv_finalize_weights(hmv_handle h) {
                 const float *q = wq->data.data(), *k = wk->data.data(), *v = wv->data.data();
                 if (cross) {
                     auto wt = [=](int o, int kk) -> float { return (o < INNER_LQ ? k : v)[(size_t)(o % INNER_LQ) * d + kk]; };
-                    L.finish(a.kv, lab + ".kv", h->ldt, 2 * INNER_LQ, 1, 1, d, wt, nullptr, nullptr, nullptr);
+                    if (x3lin) L.linear_x3(a.kv, lab + ".kv", h->ldt, 2 * INNER_LQ, d, wt);
+                    else L.finish(a.kv, lab + ".kv", h->ldt, 2 * INNER_LQ, 1, 1, d, wt, nullptr, nullptr, nullptr);
                     const HostTensor *pr = L.get(p + ".probe", {1, NJ, d});
                     if (pr) {   // q = to_q(probe + pe[:21]) in double, once
                         std::vector<float> qp((size_t)NJ * INNER_LQ);
@@ -764,7 +784,8 @@ int hmv_finalize_weights(hmv_handle h) {
                         const float *src = o < INNER_LQ ? q : (o < 2 * INNER_LQ ? k : v);
                         return src[(size_t)(o % INNER_LQ) * d + kk];
                     };
-                    L.finish(a.qkv, lab + ".qkv", h->ldt, 3 * INNER_LQ, 1, 1, d, wt, nullptr, nullptr, nullptr);
+                    if (x3lin) L.linear_x3(a.qkv, lab + ".qkv", h->ldt, 3 * INNER_LQ, d, wt);
+                    else L.finish(a.qkv, lab + ".qkv", h->ldt, 3 * INNER_LQ, 1, 1, d, wt, nullptr, nullptr, nullptr);
                 }
             }
             L.linear(a.out, lab + ".to_out", p + ".to_out.0.weight", p + ".to_out.0.bias", d, INNER_LQ);
@@ -786,7 +807,8 @@ int hmv_finalize_weights(hmv_handle h) {
                 const float *src = o < INNER ? q : (o < 2 * INNER ? k : v);
                 return src[(size_t)(o % INNER) * d + kk];
             };
-            L.finish(a.qkv, lab + ".qkv", h->ldt, 3 * INNER, 1, 1, d, wt, nullptr, nullptr, nullptr);
+            if (x3lin) L.linear_x3(a.qkv, lab + ".qkv", h->ldt, 3 * INNER, d, wt);
+            else L.finish(a.qkv, lab + ".qkv", h->ldt, 3 * INNER, 1, 1, d, wt, nullptr, nullptr, nullptr);
         }
         L.linear(a.out, lab + ".to_out", p + ".to_out.weight", p + ".to_out.bias", d, INNER);
         L.linear(a.ff1, lab + ".ff1", p + ".ff.net.1.weight", p + ".ff.net.1.bias", DHEAD, d);
@@ -1386,6 +1408,14 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
 
     float *X = tokens;
     int Tcur = V * NJ;
+    // q/k/v projection of fp32 token rows; in the fp16 / f32x3 modes on the fused split kernels (Loader::linear_x3)
+    auto project = [&](const Layer &L, const float *a, int rows, float *out, int ldc) {
+        if (!L.plane) { R.gemm(L, a, rows, out, ldc, nullptr, 0, ACT_NONE); return; }
+        float *pairs = R.alloc((size_t)rows * ldt);                        // [hi ldt | lo ldt] halfs per row
+        LAUNCH(launch_rows_f32_to_half(a, pairs, (size_t)rows, ldt, 2, s));
+        R.conv(L, pairs, rows, 1, 1, 1, 0, 0, out, ldc, nullptr, 0, ACT_NONE, 1, 1);
+        R.release(pairs);
+    };
     if (h->lq) {
         // ---- CrossAttentionFusionLearnableQuery (fusion.py:33-49; MultiHeadAttentionLearnableQuery layers.py:273-301)
         for (int l = 0; l < 5; ++l) {
@@ -1399,13 +1429,13 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
             float *o = R.alloc((size_t)qrows * ldt);
             if (cross) {
                 float *kv = R.alloc((size_t)rows * 2 * INNER_LQ);
-                R.gemm(a.kv, xp, rows, kv, 2 * INNER_LQ, nullptr, 0, ACT_NONE);
+                project(a.kv, xp, rows, kv, 2 * INNER_LQ);
                 LAUNCH(launch_attention_d256(a.qprobe, INNER_LQ, 0, kv, kv + INNER_LQ, 2 * INNER_LQ, B, Tcur, Tq, att, s));
                 R.release(kv);
                 R.gemm(a.out, att, qrows, o, ldt, nullptr, 0, ACT_NONE);   // out = to_out(att); no residual from the tokens
             } else {
                 float *qkv = R.alloc((size_t)rows * 3 * INNER_LQ);
-                R.gemm(a.qkv, xp, rows, qkv, 3 * INNER_LQ, nullptr, 0, ACT_NONE);
+                project(a.qkv, xp, rows, qkv, 3 * INNER_LQ);
                 LAUNCH(launch_attention_d256(qkv, 3 * INNER_LQ, Tcur, qkv + INNER_LQ, qkv + 2 * INNER_LQ, 3 * INNER_LQ, B, Tcur, Tq, att, s));
                 R.release(qkv);
                 R.gemm(a.out, att, qrows, o, ldt, xp, ldt, ACT_NONE);      // out = to_out(att) + x
@@ -1433,7 +1463,7 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         const int Tq = cross ? NJ : Tcur, koff = cross ? NJ : 0, Tk = cross ? Tcur - NJ : Tcur;
         const int rows = B * Tcur, qrows = B * Tq;
         float *qkv = R.alloc((size_t)rows * 3 * INNER);
-        R.gemm(a.qkv, X, rows, qkv, 3 * INNER, nullptr, 0, ACT_NONE);
+        project(a.qkv, X, rows, qkv, 3 * INNER);
         float *att = R.alloc((size_t)qrows * INNER);
         if (Tk > 0) LAUNCH(launch_attention(qkv, B, Tcur, Tq, koff, Tk, att, s));
         else LAUNCH(hipMemsetAsync(att, 0, (size_t)qrows * INNER * sizeof(float), s));

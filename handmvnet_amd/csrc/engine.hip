@@ -1080,7 +1080,7 @@ struct Runner {
         // The cut depends on K alone -- never on the batch -- so a sample's result does not depend on what it is batched with
         // (tests/test_gpu_parity.py::test_full_size_properties).  Same alloc / release sequence in the dry (planning) run.
         static const bool no_splitk = getenv("HMV_NO_SPLITK") != nullptr;   // development knob (A/B runs)
-        const int S = (!no_splitk && !L.f16 && L.R == 1 && L.S == 1 && !L.plane && L.Kpad >= 1024 && L.Kpad % 128 == 0 && rows > 0) ? 4 : 1;
+        const int S = (!no_splitk && !L.f16 && L.R == 1 && L.S == 1 && !L.plane && L.Kpad >= 1024 && L.Kpad % 128 == 0 && L.Cout <= 4096 /* zero_bias */ && rows > 0) ? 4 : 1;
         if (S == 1) {
             conv(L, a, rows, 1, 1, 1, 0, 0, out, ldc, res, ldr, act, 1, 1, rg_out, rg_in);
             return;

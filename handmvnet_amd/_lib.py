@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("HMV_LIB") or os.path.join(_HERE, "libhandmv.so")   # 
 # every symbol include/handmv.h declares
 SYMBOLS = ["hmv_create", "hmv_set_tensor", "hmv_finalize_weights", "hmv_workspace_bytes", "hmv_reserve", "hmv_forward",
            "hmv_last_error", "hmv_destroy", "hmv_set_capture", "hmv_read_stage", "hmv_set_profiling", "hmv_profile_count",
-           "hmv_profile_get", "hmv_op_conv2d", "hmv_op_conv2d_ex", "hmv_bench_conv", "hmv_pose_metrics", "hmv_forward_frames",
+           "hmv_profile_get", "hmv_op_conv2d", "hmv_op_conv2d_ex", "hmv_op_attention", "hmv_bench_conv", "hmv_pose_metrics", "hmv_forward_frames",
            "hmv_op_prepare_frames", "hmv_set_graphs", "hmv_graph_stats", "hmv_version", "hmv_profile_get_bytes"]
 
 HMV_OK = 0
@@ -64,6 +64,8 @@ def load() -> ctypes.CDLL:
     lib.hmv_op_conv2d.argtypes = [ci, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, ci, fp, ci, fp, vp]
     lib.hmv_op_conv2d_ex.argtypes = [ci, ci, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, ci, fp, ci, fp, vp]
     lib.hmv_op_conv2d_ex.restype = ctypes.c_int
+    lib.hmv_op_attention.argtypes = [ci, fp, ci, ci, ci, ci, ci, fp, vp]
+    lib.hmv_op_attention.restype = ctypes.c_int
     lib.hmv_bench_conv.argtypes = [ci] * 13 + [ctypes.POINTER(ctypes.c_float)]
     lib.hmv_bench_conv.restype = ctypes.c_int
     lib.hmv_pose_metrics.argtypes = [ci, fp, fp, ci, ci, ci, ctypes.c_float, ctypes.c_float, ci, ci, fp, fp, vp]

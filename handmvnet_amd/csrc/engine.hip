@@ -45,6 +45,7 @@ struct Layer {
     float *w = nullptr, *bias = nullptr;
     int Cin = 0, Cout = 0, R = 1, S = 1, K = 0, Kpad = 0, Cout_pad = 0;
     int Kreal = 0;      // reduction length without channel padding (FLOP accounting)
+    int in_real = 0;    // real input elements per input pixel when that is not Kreal / (R * S) (the space-to-depth stem)
     int acc_shift = 0;  // HMV_F32X3: the packed weights are W * 2^acc_shift, the epilogue scales the accumulator back
     bool x3n = false;   // HMV_F32X3: fused split reduction (one tile load per three products; conv_igemm.hip), else the cwrap scheme
     int plane = 0;      // HMV_F32X3 (split operands): physical channels per (hi | lo) plane; Cin is then the virtual 3 * plane
@@ -344,20 +345,21 @@ struct Loader {
     }
 
     // nn.Conv2d weight OIHW (+ optional bias key) followed by an optional BN
+    // (wsrc: an already re-arranged OIHW weight instead of the state_dict tensor `wkey` -- the space-to-depth stem)
     void conv(Layer &L, const std::string &label, const std::string &wkey, const std::string &bkey, const std::string &bn,
-              int Cout, int Cin, int R, int S, int cin_pad = 0, bool f16 = false, bool rd = false) {
-        const HostTensor *w = get(wkey, {Cout, Cin, R, S});
+              int Cout, int Cin, int R, int S, int cin_pad = 0, bool f16 = false, bool rd = false, const float *wsrc = nullptr) {
+        const HostTensor *w = wsrc ? nullptr : get(wkey, {Cout, Cin, R, S});
         const HostTensor *cb = bkey.empty() ? nullptr : get(bkey, {Cout});
         std::vector<double> sc, sh;
         const bool has_bn = !bn.empty();
         if (has_bn && !bn_fold(bn, Cout, sc, sh)) return;
-        if (!w || (!bkey.empty() && !cb)) return;
+        if ((!w && !wsrc) || (!bkey.empty() && !cb)) return;
         const int plane = cin_pad ? cin_pad : Cin;            // physical channels (per plane when split)
         const bool sp = split && f16;
         // fused split reduction: a k-step = 32 channels as [32 hi | 32 lo] halfs, K order (32-channel chunk, r, s, plane, c % 32)
         const bool x3n = sp && plane % 8 == 0 && !getenv("HMV_NO_X3N");
         const int cp = sp ? (x3n ? 2 * plane : 3 * plane) : plane;   // the channel count the kernel's K order walks
-        const float *wd = w->data.data();
+        const float *wd = wsrc ? wsrc : w->data.data();
         const bool chunked = cp % (f16 ? 64 : 32) == 0 && (!sp || (x3n && plane % 32 == 0) || (!x3n && plane % 64 == 0));
         auto wt = [=](int o, int k) -> float {
             int c, tap;
@@ -639,7 +641,22 @@ int hmv_finalize_weights(hmv_handle h) {
         L.conv(h->pose0, "pose_net", "pose_net.weight", "pose_net.bias", "", NJ, c.channels[0], 3, 3, cpad(c.channels[0]), h16);
     } else {
     // ---- backbone: resnet.py:162-177, 189-203
-    L.conv(h->stem, "stem", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 7, 7, /*cin_pad=*/h16 ? 8 : 4, h16);
+    {   // conv1 7x7 s2 p3 as the 4x4 s1 p2 conv over the 2x2 space-to-depth image (misc_kernels.hip, nchw_to_s2d_kernel):
+        // kernel row r reads input row 2y - 3 + r = row pair y - 2 + (r + 1) / 2, sub-row (r + 1) % 2; s2d channel (dy, dx, c)
+        const HostTensor *w7 = L.get("backbone.conv1.weight", {64, 3, 7, 7});
+        std::vector<float> ws((size_t)64 * 12 * 16, 0.f);
+        if (w7)
+            for (int o = 0; o < 64; ++o)
+                for (int c = 0; c < 3; ++c)
+                    for (int r = 0; r < 7; ++r)
+                        for (int q = 0; q < 7; ++q) {
+                            const int ty = (r + 1) >> 1, dy = (r + 1) & 1, tx = (q + 1) >> 1, dx = (q + 1) & 1;
+                            ws[(((size_t)o * 12 + (dy * 2 + dx) * 3 + c) * 4 + ty) * 4 + tx] = w7->data[(((size_t)o * 3 + c) * 7 + r) * 7 + q];
+                        }
+        L.conv(h->stem, "stem", "", "", "backbone.bn1", 64, 12, 4, 4, /*cin_pad=*/h16 ? 16 : 12, h16, false, ws.data());
+        h->stem.Kreal = 7 * 7 * 3;   // FLOP / byte accounting sees the real convolution
+        h->stem.in_real = 12;        // real input elements per (s2d) input pixel
+    }
     int inpl = 64;
     for (int li = 0; li < 3; ++li) {
         const int planes = 64 << li;
@@ -1054,7 +1071,7 @@ struct Runner {
             // A (hi, lo) pair is 4 bytes like fp32.  A strided 1x1 conv reads only the pixels it keeps.
             const double eb_in = L.f16 ? (L.plane ? 4.0 : 2.0) : 4.0;
             const double eb_out = (L.f16 && out_f16) ? (L.plane ? 4.0 : 2.0) : 4.0;
-            const double cin_real = kreal / (double)(L.R * L.S);   // (the row-decomposed form has R x S = 3 x 1 and Kreal = 3 * Cin)
+            const double cin_real = L.in_real ? (double)L.in_real : kreal / (double)(L.R * L.S);   // (the row-decomposed form has R x S = 3 x 1 and Kreal = 3 * Cin)
             const bool pointwise = L.R == 1 && L.S == 1;
             const double in_px = (pointwise && stride > 1) ? (double)p.M : (double)N * H * W;
             pr->bytes = in_px * cin_real * eb_in + (double)L.Cout * kreal * eb_in + (double)p.M * cout_real * eb_out +
@@ -1072,6 +1089,12 @@ struct Runner {
         }
     }
 
+    static int splitk_slices(const Layer &L, int rows) {
+        static const bool no_splitk = getenv("HMV_NO_SPLITK") != nullptr;   // development knob (A/B runs)
+        return (!no_splitk && !L.f16 && L.R == 1 && L.S == 1 && !L.plane && L.Kpad >= 1024 && L.Kpad % 128 == 0 &&
+                L.Cout <= 4096 /* zero_bias */ && rows > 0) ? 4 : 1;
+    }
+
     void gemm(const Layer &L, const float *a, int rows, float *out, int ldc, const float *res, int ldr, int act, int rg_out = 0,
               int rg_in = 0) {
         // split-K (layers.py:224 to_out: K = 1024, and 2048 in the learnable-query blocks): a long reduction over few token rows
@@ -1079,8 +1102,7 @@ struct Runner {
         // launch; a reduction kernel adds the partial products in slice order and applies bias / residual / activation.
         // The cut depends on K alone -- never on the batch -- so a sample's result does not depend on what it is batched with
         // (tests/test_gpu_parity.py::test_full_size_properties).  Same alloc / release sequence in the dry (planning) run.
-        static const bool no_splitk = getenv("HMV_NO_SPLITK") != nullptr;   // development knob (A/B runs)
-        const int S = (!no_splitk && !L.f16 && L.R == 1 && L.S == 1 && !L.plane && L.Kpad >= 1024 && L.Kpad % 128 == 0 && L.Cout <= 4096 /* zero_bias */ && rows > 0) ? 4 : 1;
+        const int S = splitk_slices(L, rows);
         if (S == 1) {
             conv(L, a, rows, 1, 1, 1, 0, 0, out, ldc, res, ldr, act, 1, 1, rg_out, rg_in);
             return;
@@ -1092,9 +1114,31 @@ struct Runner {
         ksplit = S;
         conv(Ls, a, rows, 1, 1, 1, 0, 0, slab, lds_, nullptr, 0, ACT_NONE, 1, 1);
         ksplit = 1;
-        if (!dry && rc == HMV_OK)
-            check(launch_splitk_reduce(slab, S, rows, lds_, L.Cout, L.bias, res, ldr, rg_out, rg_in, act, out, ldc, s), "splitk_reduce");
+        if (!dry && rc == HMV_OK) {
+            if (ln.y)   // the consumer is a LayerNorm (gemm_ln below): slice sum, bias and residual become its load
+                check(launch_splitk_layernorm(slab, S, rows, lds_, L.Cout, L.bias, res, ldr, rg_out, rg_in, ln.g1, ln.b1, ln.y, ln.ldy,
+                                              ln.g2, ln.b2, ln.y2, s), "splitk_layernorm");
+            else
+                check(launch_splitk_reduce(slab, S, rows, lds_, L.Cout, L.bias, res, ldr, rg_out, rg_in, act, out, ldc, s), "splitk_reduce");
+        }
         release(slab);
+    }
+
+    // y = LayerNorm(a . W + bias + residual) (+ a chained second LayerNorm y2): layers.py:224-229 (to_out, + _q, norm1, then the
+    // FeedForward's own LayerNorm).  With split-K the GEMM's reduction kernel IS the LayerNorm kernel (one launch less per block).
+    struct LnTail { const float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr; float *y = nullptr, *y2 = nullptr; int ldy = 0; } ln;
+    void gemm_ln(const Layer &L, const float *a, int rows, const float *res, int ldr, int rg_out, int rg_in, const float *g1,
+                 const float *b1, float *y, int ldy, const float *g2, const float *b2, float *y2) {
+        if (splitk_slices(L, rows) > 1) {
+            ln.g1 = g1; ln.b1 = b1; ln.g2 = g2; ln.b2 = b2; ln.y = y; ln.y2 = y2; ln.ldy = ldy;
+            gemm(L, a, rows, nullptr, 0, res, ldr, ACT_NONE, rg_out, rg_in);
+            ln = LnTail();
+            return;
+        }
+        float *o = alloc((size_t)rows * ldy);
+        gemm(L, a, rows, o, ldy, res, ldr, ACT_NONE, rg_out, rg_in);
+        if (!dry && rc == HMV_OK) check(launch_layernorm(o, ldy, rows, L.Cout, g1, b1, y, ldy, g2, b2, y2, s), "layernorm");
+        release(o);
     }
 };
 
@@ -1263,15 +1307,14 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         R.conv(h->pose0, lvl[0], N, lvh[0], lvw[0], 2, 1, 1, hm, 32, nullptr, 0, ACT_NONE, hmh, hmw);
     } else {
     // ---- stem: conv1 7x7 s2 + BN + ReLU, maxpool 3x3 s2 (resnet.py:218-221)
-    // NHWC4 fp32 and NHWC8 fp16 are both 16 bytes per pixel; split pairs [hi8 | lo8] take 32
-    float *in4 = R.alloc((size_t)N * H * W * (split ? 8 : 4));
-    if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, split ? 2 : (h16 ? 1 : 0), in4, s));
-    else if (split) LAUNCH(launch_nchw_to_nhwc_split(x, in4, N, H, W, s));
-    else if (h16) LAUNCH(launch_nchw_to_nhwc8_f16(x, in4, N, H, W, s));
-    else LAUNCH(launch_nchw_to_nhwc4(x, in4, N, H, W, s));
-    const int H1 = (H + 6 - 7) / 2 + 1, W1 = (W + 6 - 7) / 2 + 1;
+    // as a 4x4 stride-1 conv over the 2x2 space-to-depth frames: 12 fp32 / 16 fp16 (12 + 4 zeros) / [hi16 | lo16] per s2d pixel
+    const int Hs = (H + 1) / 2, Ws = (W + 1) / 2, smode = split ? 2 : (h16 ? 1 : 0);
+    float *in4 = R.alloc((size_t)N * Hs * Ws * (split ? 16 : (h16 ? 8 : 12)));
+    if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, smode, in4, s, /*s2d=*/true));
+    else LAUNCH(launch_nchw_to_s2d(x, in4, N, H, W, smode, s));
+    const int H1 = (H + 6 - 7) / 2 + 1, W1 = (W + 6 - 7) / 2 + 1;   // == Hs, Ws
     float *c1 = R.alloc(ACT((size_t)N * H1 * W1 * 64));
-    R.conv(h->stem, in4, N, H, W, 2, 3, 3, c1, 64, nullptr, 0, ACT_RELU, H1, W1, 0, 0, 0, 0, 0, h16);
+    R.conv(h->stem, in4, N, Hs, Ws, 1, 2, 2, c1, 64, nullptr, 0, ACT_RELU, H1, W1, 0, 0, 0, 0, 0, h16);
     R.release(in4);
     int hh = (H1 + 2 - 3) / 2 + 1, ww = (W1 + 2 - 3) / 2 + 1, C = 64;
     float *cur = R.alloc(ACT((size_t)N * hh * ww * 64));
@@ -1468,12 +1511,9 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         if (Tk > 0) LAUNCH(launch_attention(qkv, B, Tcur, Tq, koff, Tk, att, s));
         else LAUNCH(hipMemsetAsync(att, 0, (size_t)qrows * INNER * sizeof(float), s));
         R.release(qkv);
-        float *o = R.alloc((size_t)qrows * ldt);
-        R.gemm(a.out, att, qrows, o, ldt, X, ldt, ACT_NONE, cross ? Tq : 0, cross ? Tcur : 0);  // + _q
-        R.release(att);
         float *n1 = R.alloc((size_t)qrows * ldt), *f0 = R.alloc((size_t)qrows * ldt);
-        LAUNCH(launch_layernorm(o, ldt, qrows, d, a.n1g, a.n1b, n1, ldt, a.fg, a.fb, f0, s));
-        R.release(o);
+        R.gemm_ln(a.out, att, qrows, X, ldt, cross ? Tq : 0, cross ? Tcur : 0, a.n1g, a.n1b, n1, ldt, a.fg, a.fb, f0);  // norm1(to_out + _q), ff LN
+        R.release(att);
         float *f1 = R.alloc((size_t)qrows * DHEAD);
         R.gemm(a.ff1, f0, qrows, f1, DHEAD, nullptr, 0, ACT_GELU);
         R.release(f0);
@@ -1764,6 +1804,18 @@ int hmv_profile_get(hmv_handle h, int32_t index, const char **name, const char *
 int hmv_profile_get_bytes(hmv_handle h, int32_t index, double *bytes) {
     if (!h || index < 0 || (size_t)index >= h->prof_used || !bytes) return HMV_ERR_ARG;
     *bytes = h->prof[index].bytes;
+    return HMV_OK;
+}
+
+int hmv_op_attention(int32_t device, const float *qkv, int32_t B, int32_t T, int32_t Tq, int32_t koff, int32_t Tk, float *out,
+                     void *stream) {
+    if (!qkv || !out || B <= 0 || T <= 0 || Tq <= 0 || Tq > T || Tk <= 0 || koff < 0 || koff + Tk > T) {
+        g_create_err = "hmv_op_attention: bad argument";
+        return HMV_ERR_ARG;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
+    const hipError_t e = launch_attention(qkv, B, T, Tq, koff, Tk, out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) { g_create_err = std::string("attention launch failed: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
     return HMV_OK;
 }
 

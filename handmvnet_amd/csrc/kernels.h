@@ -96,8 +96,10 @@ hipError_t launch_nchw_to_nhwc8_f16(const float *x, void *out, int N, int H, int
 // uint8 HWC camera frames + integer crop windows -> normalised NHWC4 fp32 / NHWC8 fp16 stem input (ho3d.py:35-40, 136-149)
 // out_mode: 0 = NHWC4 fp32, 1 = NHWC8 fp16, 2 = split [hi8 | lo8] fp16 pairs (HMV_F32X3)
 hipError_t launch_frames_to_input(const uint8_t *frames, const int *boxes, int N, int Hf, int Wf, int S_h, int S_w, const float *mean,
-                                  const float *std, int out_mode, void *out, hipStream_t s);
+                                  const float *std, int out_mode, void *out, hipStream_t s, bool s2d = false);
 // HMV_F32X3 helpers: tensors whose rows are [hi plane | lo plane] fp16 pairs
+// space-to-depth stem input (misc_kernels.hip): mode 0 fp32 [12], 1 fp16 [16], 2 split [hi16 | lo16] per 2x2 pixel block
+hipError_t launch_nchw_to_s2d(const float *x, void *out, int N, int H, int W, int mode, hipStream_t s);
 hipError_t launch_nchw_to_nhwc_split(const float *x, void *out, int N, int H, int W, hipStream_t s);
 hipError_t launch_maxpool3s2_split(const void *in, void *out, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 hipError_t launch_nhwc_split_to_nchw(const void *in, float *out, int N, int H, int W, int C, hipStream_t s);
@@ -125,6 +127,9 @@ hipError_t launch_attention_d256(const float *q, int q_ld, int q_bstride, const 
 // y[r][c] = x[r][c] + pe[r % T][c] for c < d, 0 for d <= c < ldy (PositionalEncoding inside every learnable-query block)
 hipError_t launch_add_pe(const float *x, int ldx, int rows, int T, int d, const float *pe, float *y, int ldy, hipStream_t s);
 // split-K GEMM tail: out[r][c] = act(sum_s slab[s][r][c] + bias[c] + res[r'][c]) for c < N (slices summed in index order)
+hipError_t launch_splitk_layernorm(const float *slab, int S, int rows, int lds, int d, const float *bias, const float *res, int ldr,
+                                   int rg_out, int rg_in, const float *g1, const float *b1, float *y, int ldy, const float *g2,
+                                   const float *b2, float *y2, hipStream_t s);
 hipError_t launch_splitk_reduce(const float *slab, int S, int rows, int lds, int N, const float *bias, const float *res, int ldr,
                                 int rg_out, int rg_in, int act, float *out, int ldc, hipStream_t s);
 // Chebyshev mix: out[b][i][o] = act(sum_k sum_j Tk[k][i][j] * y[b*21+j][k*co + o] + bias[o])

@@ -124,6 +124,70 @@ hipError_t launch_nchw_to_nhwc_split(const float *x, void *out, int N, int H, in
     hipLaunchKernelGGL(nchw_to_nhwc_split_kernel, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<f16x8 *>(out), H * W, total);
     return hipGetLastError();
 }
+// ------------------------------------------------------------------ space-to-depth stem input (ResNet backbones, round 2)
+// conv1 7x7 stride 2 pad 3 over 3 channels == a 4x4 stride-1 pad-2 conv over the 2x2 space-to-depth image with 12 channels
+// whose extra (8th) row / column of weights is zero: input row 2y - 3 + r is row pair y - 2 + (r + 1) / 2, sub-row (r + 1) % 2.
+// The reduction shrinks from 7 x 7 x 4 (pad channel) = 196 -> 224 executed to 192 (fp32), from 7 x 7 x 8 = 392 -> 448 to
+// 4 x 4 x 16 = 256 (fp16), and every 16-byte vector the dense-K gather moves is 75-100 % real data instead of 37-75 %.
+// Channel order inside an s2d pixel: (dy, dx, c).  MODE 0: fp32 [12]; 1: fp16 [12 + 4 zeros]; 2: split [hi 16 | lo 16].
+// Rows / columns beyond an odd H / W are zeros.
+template <int MODE>
+__device__ __forceinline__ void s2d_store(void *__restrict__ out, size_t q, const float (&v)[12]) {
+    if (MODE == 0) {
+        f32x4 *o = reinterpret_cast<f32x4 *>(out) + 3 * q;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[j] = f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+    } else if (MODE == 1) {
+        f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0}, b = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (_Float16)v[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = (_Float16)v[8 + j];
+        f16x8 *o = reinterpret_cast<f16x8 *>(out) + 2 * q;
+        o[0] = a; o[1] = b;
+    } else {
+        f16x8 h0 = {0, 0, 0, 0, 0, 0, 0, 0}, h1 = h0, l0 = h0, l1 = h0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            _Float16 a, b;
+            split_f16(v[j], a, b);
+            if (j < 8) { h0[j] = a; l0[j] = b; } else { h1[j - 8] = a; l1[j - 8] = b; }
+        }
+        f16x8 *o = reinterpret_cast<f16x8 *>(out) + 4 * q;
+        o[0] = h0; o[1] = h1; o[2] = l0; o[3] = l1;
+    }
+}
+template <int MODE>
+__global__ void nchw_to_s2d_kernel(const float *__restrict__ x, void *__restrict__ out, int H, int W, int Hs, int Ws, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int xs = (int)(i % Ws);
+        size_t t = i / Ws;
+        const int ys = (int)(t % Hs);
+        const size_t n = t / Hs;
+        float v[12];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int yy = 2 * ys + dy, xx = 2 * xs + dx;
+                const bool in = yy < H && xx < W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[(dy * 2 + dx) * 3 + c] = in ? x[((n * 3 + c) * H + yy) * (size_t)W + xx] : 0.f;
+            }
+        s2d_store<MODE>(out, i, v);
+    }
+}
+hipError_t launch_nchw_to_s2d(const float *x, void *out, int N, int H, int W, int mode, hipStream_t s) {
+    const int Hs = (H + 1) / 2, Ws = (W + 1) / 2;
+    const size_t total = (size_t)N * Hs * Ws;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (mode == 2) hipLaunchKernelGGL(nchw_to_s2d_kernel<2>, dim3(grid), dim3(256), 0, s, x, out, H, W, Hs, Ws, total);
+    else if (mode == 1) hipLaunchKernelGGL(nchw_to_s2d_kernel<1>, dim3(grid), dim3(256), 0, s, x, out, H, W, Hs, Ws, total);
+    else hipLaunchKernelGGL(nchw_to_s2d_kernel<0>, dim3(grid), dim3(256), 0, s, x, out, H, W, Hs, Ws, total);
+    return hipGetLastError();
+}
 // fp32 rows [rows][C] -> fp16 rows [rows][C] (mode 1) or split rows [rows][hi C | lo C] (mode 2): op-level tests
 __global__ void rows_f32_to_half_kernel(const float *__restrict__ in, _Float16 *__restrict__ out, int C, int mode, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -332,11 +396,13 @@ __global__ void sample_gather_kernel(const f32x4 *__restrict__ feat, int H, int 
     const int row = blockIdx.x;  // n*21 + j
     const int n = row / 21;
     const Taps t = bilinear_taps(coords[2 * row], coords[2 * row + 1], H, W);
+    // (no t.v[tap]: a run-time index would put the struct into scratch memory -- 29 us for this 5 us copy)
+    const unsigned vmask = (t.v[0] ? 1u : 0u) | (t.v[1] ? 2u : 0u) | (t.v[2] ? 4u : 0u) | (t.v[3] ? 8u : 0u);
     for (int i = threadIdx.x; i < 4 * C4; i += blockDim.x) {
         const int tap = i / C4, c = i - tap * C4;
         const int x = t.x0 + (tap & 1), y = t.y0 + (tap >> 1);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (t.v[tap]) v = feat[(((size_t)n * H + y) * W + x) * C4 + c];
+        if ((vmask >> tap) & 1u) v = feat[(((size_t)n * H + y) * W + x) * C4 + c];
         out[((size_t)row * 4 + tap) * C4 + c] = v;
     }
 }
@@ -414,18 +480,39 @@ hipError_t launch_tokens_finalize(float *tokens, int ldt, int d, int fdim, int N
 // layers.py:194-195 (norm1/norm2), layers.py:165 (FeedForward's leading LayerNorm); eps 1e-5.
 // One wave per row, two-pass (mean, then centred variance) in registers.
 constexpr int LN_MAX_PER_LANE = 16;  // d <= 1024
+// SK: the row is not read from x but assembled from the S partial products of a split-K GEMM (slices added in index order,
+// then bias, then the residual row -- the arithmetic of splitk_reduce_kernel, so both forms give the same bits)
+struct LnSplitK { const float *slab; int S; size_t slice; int lds; const float *bias; const float *res; int ldr, rg_out, rg_in; };
+template <int SK>   // 0: plain rows; otherwise the number of split-K slices
 __global__ void layernorm_kernel(const float *__restrict__ x, int ldx, int rows, int d, const float *__restrict__ g1,
                                  const float *__restrict__ b1, float *__restrict__ y, int ldy,
-                                 const float *__restrict__ g2, const float *__restrict__ b2, float *__restrict__ y2) {
+                                 const float *__restrict__ g2, const float *__restrict__ b2, float *__restrict__ y2, LnSplitK sk) {
     const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const float *xr = x + (size_t)row * ldx;
+    const float *xr = SK ? nullptr : x + (size_t)row * ldx;
+    const float *rr = nullptr;
+    if (SK && sk.res) rr = sk.res + (size_t)(sk.rg_out ? (row / sk.rg_out) * sk.rg_in + (row % sk.rg_out) : row) * sk.ldr;
     float v[LN_MAX_PER_LANE];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
         const int c = lane + 64 * i;
-        v[i] = c < d ? xr[c] : 0.f;
+        if (SK) {
+            float t = 0.f;
+            if (c < d) {
+                float part[SK ? SK : 1];
+#pragma unroll
+                for (int k = 0; k < SK; ++k) part[k] = sk.slab[k * sk.slice + (size_t)row * sk.lds + c];   // independent loads
+                const float bb = sk.bias[c], rv = rr ? rr[c] : 0.f;
+#pragma unroll
+                for (int k = 0; k < SK; ++k) t += part[k];
+                t += bb;
+                if (rr) t += rv;
+            }
+            v[i] = t;
+        } else {
+            v[i] = c < d ? xr[c] : 0.f;
+        }
         s += v[i];
     }
     const float inv_d = 1.f / (float)d;
@@ -469,142 +556,217 @@ __global__ void layernorm_kernel(const float *__restrict__ x, int ldx, int rows,
 hipError_t launch_layernorm(const float *x, int ldx, int rows, int d, const float *g1, const float *b1, float *y, int ldy,
                             const float *g2, const float *b2, float *y2, hipStream_t s) {
     if (d > 64 * LN_MAX_PER_LANE || ldy > 64 * LN_MAX_PER_LANE) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, d, g1, b1, y, ldy, g2, b2, y2);
+    hipLaunchKernelGGL(layernorm_kernel<0>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, rows, d, g1, b1, y, ldy, g2, b2, y2, LnSplitK{});
+    return hipGetLastError();
+}
+hipError_t launch_splitk_layernorm(const float *slab, int S, int rows, int lds, int d, const float *bias, const float *res, int ldr,
+                                   int rg_out, int rg_in, const float *g1, const float *b1, float *y, int ldy, const float *g2,
+                                   const float *b2, float *y2, hipStream_t s) {
+    if (d > 64 * LN_MAX_PER_LANE || ldy > 64 * LN_MAX_PER_LANE || S != 4 || !slab || !bias) return hipErrorInvalidValue;
+    if (!rows) return hipSuccess;
+    const LnSplitK sk{slab, S, (size_t)rows * lds, lds, bias, res, ldr, rg_out, rg_in};
+    hipLaunchKernelGGL(layernorm_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, s, nullptr, 0, rows, d, g1, b1, y, ldy, g2, b2, y2, sk);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ attention on the fp32 matrix cores
 // layers.py:216-221: dots = q k^T * 128^-0.5 ; softmax over keys ; out = attn v      (8 heads x 128)
-// One workgroup (4 waves) per (sample, head).  Flash-style: keys are walked in chunks of 32; the K and V
-// chunks are staged through LDS once per workgroup and shared by the 4 waves; each wave owns 32-row query
-// blocks (q-block w, w+4, ... in successive passes) with Q held in registers as the MFMA A operand.
-//   S  = Q_blk K_chunk^T   64 x v_mfma_f32_32x32x2_f32 (k = 128)          -> 16 accumulator registers
-//   online softmax: running row max via 5 wave shuffles per accumulator register, running row sum kept
-//   lane-private (one column per lane) and reduced across lanes once at the end
-//   P (C layout, key on the lane) -> per-wave LDS scratch -> A layout (query row on the lane)
-//   O += P V_chunk          64 x MFMA (4 channel blocks x 16 k-pairs)     -> 64 accumulator registers
+// One workgroup (4 waves) per (sample, head, 32-row query block); the 32-key chunks of the key range are dealt round-robin
+// to the 4 waves (wave w: chunks w, w + 4, ...), each wave runs the flash recurrence over ITS chunks, and the four partial
+// (max, sum, O) triples are merged through LDS at the end.  Nothing depends on the batch.
+// Everything is computed TRANSPOSED, so that a query row lives on a lane instead of across lanes:
+//   S^T = K_chunk Q_blk^T   64 x v_mfma_f32_32x32x2_f32 (k = 128): A = the lane's own key row straight from global memory,
+//                           B = Q block from LDS (staged once per workgroup).  Lane (q, half) then holds the logits of query q
+//                           against 16 of the chunk's 32 keys in its 16 accumulator registers
+//   online softmax          row max = max over the lane's 16 registers + ONE cross-half exchange (the round-1 form, key on the
+//                           lane, needed 80 dependent wave shuffles per chunk and a P round trip through LDS: a 13 us floor
+//                           per launch); running max / sum / rescale factor are one register each
+//   O^T += V_chunk^T P^T    64 x MFMA: A = V rows from a per-wave LDS buffer (channel on the lane), B = P^T -- which is exactly
+//                           the accumulator layout S^T came out in, so P never leaves the registers
 // The k order inside every 8-wide group is permuted identically for both operands (16-byte reads).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int ATT_LDK = 132;   // K chunk row stride (floats): conflict-free ds_read_b128 of the B operand
-constexpr int ATT_LDP = 36;    // P scratch row stride
-constexpr int ATT_WAVES = 8;   // 8 waves = 8 query blocks (256 query rows) per pass: T = 168 (8 views) is ONE pass
-constexpr int ATT_LDS_FLOATS = 32 * ATT_LDK + 32 * 128 + ATT_WAVES * 32 * ATT_LDP;
+constexpr int ATT_LDK = 132;   // Q block row stride (floats): conflict-free ds_read_b128 of the B operand
+constexpr int ATT_WAVES = 4;
+constexpr int ATT_Q_FLOATS = 32 * ATT_LDK;
+constexpr int ATT_V_FLOATS = 8 * 128;                        // per wave: a quarter of a chunk
+constexpr int ATT_LOOP_FLOATS = ATT_Q_FLOATS + ATT_WAVES * ATT_V_FLOATS;
+constexpr int ATT_MERGE_FLOATS = ATT_WAVES * 64 * 64 + 2 * ATT_WAVES * 32;   // O partials [w][c][e][lane], then max and sum [w][query]
+constexpr int ATT_LDS_FLOATS = ATT_LOOP_FLOATS > ATT_MERGE_FLOATS ? ATT_LOOP_FLOATS : ATT_MERGE_FLOATS;
 
-// Round 2: 8 waves per (sample, head) instead of 4: the 6 query blocks of an 8-view sample no longer need a second,
-// half-empty pass that re-stages every K / V chunk.  The arithmetic of a query block is unchanged (bit-identical results).
-__global__ __launch_bounds__(64 * ATT_WAVES) void attention_mfma_kernel(const float *__restrict__ qkv, int T, int Tq, int koff, int Tk,
-                                                                        float *__restrict__ out) {
+#ifndef HMV_ATT_OCC
+#define HMV_ATT_OCC 2   // workgroups per CU the register budget is set for
+#endif
+__global__ __launch_bounds__(64 * ATT_WAVES, HMV_ATT_OCC) void attention_mfma_kernel(const float *__restrict__ qkv, int T, int Tq, int koff, int Tk,
+                                                                           int nqb, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float att_smem[];
-    float *sK = att_smem;                       // [32][ATT_LDK]
-    float *sV = sK + 32 * ATT_LDK;              // [32][128]
-    float *sPall = sV + 32 * 128;               // [ATT_WAVES][32][ATT_LDP]
-    const int b = blockIdx.x >> 3, h = blockIdx.x & 7;
+    const int qblk = blockIdx.x % nqb, bh = blockIdx.x / nqb;
+    const int b = bh >> 3, h = bh & 7;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const size_t ld = 3 * 1024;
     const float *base = qkv + (size_t)b * T * ld;
     const float *qb = base + h * 128, *kb = base + (size_t)koff * ld + 1024 + h * 128, *vb = base + (size_t)koff * ld + 2048 + h * 128;
-    const int nqb = (Tq + 31) >> 5, nkc = (Tk + 31) >> 5;
+    const int nkc = (Tk + 31) >> 5;
     const float scale = 0.08838834764831845f;  // 128 ** -0.5
-    float *pw = sPall + wave * 32 * ATT_LDP;
-    constexpr int NST = 1024 / (64 * ATT_WAVES);   // 16-byte vectors of K (and as many of V) each thread stages per chunk
+    float *sQ = att_smem;                                                   // [32][ATT_LDK]
+    float *sVw = att_smem + ATT_Q_FLOATS + wave * ATT_V_FLOATS;             // [8][128], this wave's
 
-    for (int pass = 0; pass * ATT_WAVES < nqb; ++pass) {
-        const int qblk = pass * ATT_WAVES + wave;
-        const bool active = qblk < nqb;              // wave-uniform
-        const int qrow = qblk * 32 + l31;
-        // Q block as the A operand: lane (row l31, k-half kh) holds Q[row][8u + 4kh + e]
-        f32x4 qa[16];
+    // every global load of a wave's first chunk is issued before anything waits
+    f32x4 kf[16], va[4], vb_[4];
+    int kc = wave;
+#define ATT_LOAD_K(KC)                                                                                  \
+    do {                                                                                                \
+        const int key_ = (KC) * 32 + l31;                                                               \
+        const bool kv_ = key_ < Tk;                                                                     \
+        const float *krow_ = kb + (size_t)(kv_ ? key_ : 0) * ld + 4 * kh;                               \
+        _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                                \
+            kf[u] = *reinterpret_cast<const f32x4 *>(krow_ + 8 * u);                                    \
+            if (!kv_) kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+        }                                                                                               \
+    } while (0)
+    // 8 keys x 128 channels: 4 coalesced 16-byte vectors per lane (keys >= Tk are zeros)
+#define ATT_LOAD_V(KEY0, VR)                                                                            \
+    do {                                                                                                \
+        _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                              \
+            const int idx_ = it * 64 + lane, k2_ = (KEY0) + (idx_ >> 5);                                \
+            VR[it] = f32x4{0.f, 0.f, 0.f, 0.f};                                                         \
+            if (k2_ < Tk) VR[it] = *reinterpret_cast<const f32x4 *>(vb + (size_t)k2_ * ld + 4 * (idx_ & 31)); \
+        }                                                                                               \
+    } while (0)
+#define ATT_STORE_V(VR)                                                                                 \
+    do {                                                                                                \
+        __builtin_amdgcn_wave_barrier();                                                                \
+        _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                              \
+            const int idx_ = it * 64 + lane;                                                            \
+            *reinterpret_cast<f32x4 *>(&sVw[(idx_ >> 5) * 128 + 4 * (idx_ & 31)]) = VR[it];             \
+        }                                                                                               \
+        __builtin_amdgcn_wave_barrier();                                                                \
+    } while (0)
+    // O^T += V^T P^T over the 8 keys of quarter G: the k-pair of step e2 is (key 8G + e2, key 8G + e2 + 4) = P register 4G + e2
+#define ATT_PV(G)                                                                                       \
+    do {                                                                                                \
+        _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                              \
+            const float *vrow = &sVw[(4 * kh + e2) * 128 + l31];                                        \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c)                                               \
+                o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * c], sacc[4 * (G) + e2], o[c], 0, 0, 0); \
+        }                                                                                               \
+    } while (0)
+    if (kc < nkc) {
+        ATT_LOAD_K(kc);
+        ATT_LOAD_V(kc * 32, va);
+    }
+    // Q block (rows >= Tq are zeros), shared by the 4 waves
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            qa[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (active && qrow < Tq) qa[u] = *reinterpret_cast<const f32x4 *>(qb + (size_t)qrow * ld + 8 * u + 4 * kh);
-        }
-        f32x16 o[4];
-        float m_run[16], l_run[16];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[c][e] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { m_run[e] = -INFINITY; l_run[e] = 0.f; }
+    for (int it = 0; it < 4; ++it) {
+        const int idx = it * 256 + tid, r = idx >> 5, c4 = idx & 31, row = qblk * 32 + r;
+        f32x4 q = {0.f, 0.f, 0.f, 0.f};
+        if (row < Tq) q = *reinterpret_cast<const f32x4 *>(qb + (size_t)row * ld + 4 * c4);
+        *reinterpret_cast<f32x4 *>(&sQ[r * ATT_LDK + 4 * c4]) = q;
+    }
+    __syncthreads();
 
-        for (int kc = 0; kc < nkc; ++kc) {
-            __syncthreads();   // previous chunk fully consumed
-            // stage K and V chunk (32 keys x 128 dims each = 1024 + 1024 16-byte vectors); keys >= Tk are zeros
+    f32x16 o[4];   // o[c][e] on lane (q, half): O[q][32c + (e&3) + 8(e>>2) + 4 half]
+    float m_run = -INFINITY, l_run = 0.f;   // of query l31, over the keys this lane has seen (its half of every chunk)
 #pragma unroll
-            for (int it = 0; it < NST; ++it) {
-                const int idx = it * 64 * ATT_WAVES + tid, j = idx >> 5, c4 = idx & 31, key = kc * 32 + j;
-                f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-                if (key < Tk) {
-                    kv = *reinterpret_cast<const f32x4 *>(kb + (size_t)key * ld + 4 * c4);
-                    vv = *reinterpret_cast<const f32x4 *>(vb + (size_t)key * ld + 4 * c4);
-                }
-                *reinterpret_cast<f32x4 *>(&sK[j * ATT_LDK + 4 * c4]) = kv;
-                *reinterpret_cast<f32x4 *>(&sV[j * 128 + 4 * c4]) = vv;
-            }
-            __syncthreads();
-            if (!active) continue;
-            // ---- S = Q K^T (32 x 32), key on the lane
-            f32x16 sacc;
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const f32x4 kf = *reinterpret_cast<const f32x4 *>(&sK[l31 * ATT_LDK + 8 * u + 4 * kh]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[u][e], kf[e], sacc, 0, 0, 0);
-            }
-            // ---- online softmax.  Register e holds row (e&3) + 8*(e>>2) + 4*kh, column = this lane's key
-            const bool kvalid = kc * 32 + l31 < Tk;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float sv = kvalid ? sacc[e] * scale : -INFINITY;
-                float mx = sv;
-#pragma unroll
-                for (int ofs = 16; ofs > 0; ofs >>= 1) mx = fmaxf(mx, __shfl_xor(mx, ofs, 64));   // stays inside the 32-lane half
-                const float m_new = fmaxf(m_run[e], mx);                                        // finite: chunk has >= 1 valid key
-                const float alpha = expf(m_run[e] - m_new);                                        // exp(-inf) = 0 on the first chunk
-                const float pe = kvalid ? expf(sv - m_new) : 0.f;
-                l_run[e] = l_run[e] * alpha + pe;
-                m_run[e] = m_new;
-                pw[((e & 3) + 8 * (e >> 2) + 4 * kh) * ATT_LDP + l31] = pe;                     // P[row][key]
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[c][e] *= alpha;
-            }
-            __builtin_amdgcn_wave_barrier();
-            // ---- O += P V: A = P (query row on the lane), B = V chunk (channel on the lane)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 pf = *reinterpret_cast<const f32x4 *>(&pw[l31 * ATT_LDP + 8 * u + 4 * kh]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float *vrow = &sV[(8 * u + 4 * kh + e) * 128 + l31];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[e], vrow[32 * c], o[c], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+        for (int e = 0; e < 16; ++e) o[c][e] = 0.f;
+
+#define ATT_CHUNK(KC)                                                                                   \
+    do {                                                                                                \
+        f32x16 sacc;                                                                                    \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) sacc[e] = 0.f;                                   \
+        _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                                \
+            const f32x4 qf = *reinterpret_cast<const f32x4 *>(&sQ[l31 * ATT_LDK + 8 * u + 4 * kh]);     \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                               \
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[e], sacc, 0, 0, 0);            \
+        }                                                                                               \
+        ATT_LOAD_V((KC) * 32 + 8, vb_);   /* the next 8 keys fly during the softmax */                  \
+        /* register e = key (e&3) + 8(e>>2) + 4 half of the chunk, for query l31 */                     \
+        float mx = -INFINITY;                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                \
+            const bool kv_ = (KC) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh < Tk;                          \
+            sacc[e] = kv_ ? sacc[e] * scale : -INFINITY;                                                \
+            mx = fmaxf(mx, sacc[e]);                                                                    \
+        }                                                                                               \
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          /* finite: the chunk has >= 1 valid key */     \
+        const float m_new = fmaxf(m_run, mx);                                                           \
+        const float alpha = expf(m_run - m_new);         /* exp(-inf) = 0 on the first chunk */         \
+        float psum = 0.f;                                                                               \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                \
+            sacc[e] = expf(sacc[e] - m_new);             /* exp(-inf) = 0 for keys >= Tk */             \
+            psum += sacc[e];                                                                            \
+        }                                                                                               \
+        l_run = l_run * alpha + psum;                                                                   \
+        m_run = m_new;                                                                                  \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                   \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) o[c][e] *= alpha;                            \
+        /* 8 keys at a time through the wave's LDS buffer; the loads run two quarters ahead */          \
+        ATT_STORE_V(va);                                                                                \
+        ATT_LOAD_V((KC) * 32 + 16, va);                                                                 \
+        ATT_PV(0);                                                                                      \
+        ATT_STORE_V(vb_);                                                                               \
+        ATT_LOAD_V((KC) * 32 + 24, vb_);                                                                \
+        ATT_PV(1);                                                                                      \
+        ATT_STORE_V(va);                                                                                \
+        ATT_PV(2);                                                                                      \
+        ATT_STORE_V(vb_);                                                                               \
+        ATT_PV(3);                                                                                      \
+        __builtin_amdgcn_wave_barrier();                                                                \
+    } while (0)
+    if (kc < nkc) {
+        ATT_CHUNK(kc);
+        for (kc += ATT_WAVES; kc < nkc; kc += ATT_WAVES) {
+            ATT_LOAD_K(kc);
+            ATT_LOAD_V(kc * 32, va);
+            ATT_CHUNK(kc);
         }
-        if (active) {
+    }
+#undef ATT_CHUNK
+#undef ATT_LOAD_K
+#undef ATT_LOAD_V
+#undef ATT_STORE_V
+#undef ATT_PV
+
+    // ---- merge the 4 waves' partials in wave order: out = sum_w O_w e^(m_w - M) / sum_w l_w e^(m_w - M)
+    __syncthreads();   // the merge area aliases the loop's buffers
+    float *sO = att_smem, *sM = att_smem + ATT_WAVES * 64 * 64, *sL = sM + ATT_WAVES * 32;
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (kh == 0) { sM[wave * 32 + l31] = m_run; sL[wave * 32 + l31] = l_run; }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float l = l_run[e];
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int ofs = 16; ofs > 0; ofs >>= 1) l += __shfl_xor(l, ofs, 64);
-                const float inv = 1.f / l;
-                const int row = qblk * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                if (row < Tq) {
-                    float *orow = out + ((size_t)b * Tq + row) * 1024 + h * 128 + l31;
+        for (int e = 0; e < 16; ++e) sO[((wave * 4 + c) * 16 + e) * 64 + lane] = o[c][e];
+    __syncthreads();
+    {
+        const int c = wave;   // this wave finishes channel block c
+        float M = sM[l31];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) orow[32 * c] = o[c][e] * inv;
-                }
+        for (int w = 1; w < ATT_WAVES; ++w) M = fmaxf(M, sM[w * 32 + l31]);
+        float a[ATT_WAVES], den = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) {
+            a[w] = expf(sM[w * 32 + l31] - M);   // exp(-inf) = 0 for a wave that had no chunk
+            den += sL[w * 32 + l31] * a[w];
+        }
+        const float inv = 1.f / den;
+        const int row = qblk * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 r4;
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                float num = 0.f;
+#pragma unroll
+                for (int w = 0; w < ATT_WAVES; ++w) num += sO[((w * 4 + c) * 16 + 4 * g + e2) * 64 + lane] * a[w];
+                r4[e2] = num * inv;
             }
+            if (row < Tq) *reinterpret_cast<f32x4 *>(out + ((size_t)b * Tq + row) * 1024 + h * 128 + 32 * c + 8 * g + 4 * kh) = r4;
         }
     }
 }
 hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s) {
-    if (Tk <= 0 || Tq <= 0) return hipErrorInvalidValue;
+    if (Tk <= 0 || Tq <= 0 || B <= 0) return hipErrorInvalidValue;
     static bool configured[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -614,7 +776,8 @@ hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, in
         if (e != hipSuccess) return e;
         configured[dev] = true;
     }
-    hipLaunchKernelGGL(attention_mfma_kernel, dim3(B * 8), dim3(64 * ATT_WAVES), lds, s, qkv, T, Tq, koff, Tk, out);
+    const int nqb = (Tq + 31) >> 5;
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)B * 8 * nqb), dim3(64 * ATT_WAVES), lds, s, qkv, T, Tq, koff, Tk, nqb, out);
     return hipGetLastError();
 }
 
@@ -722,19 +885,22 @@ hipError_t launch_splitk_reduce(const float *slab, int S, int rows, int lds, int
 
 // ------------------------------------------------------------------ ChebConv mix
 // layers.py:387-403: sum_k T_k (X W_k) + b, the X W_k products come from one GEMM with N = 3*co.
+// One workgroup per (sample, 32-channel slice): 8 joints x 32 channels per pass (the previous one-workgroup-per-sample form
+// left a small batch on B CUs, 21 serial outputs per thread).  Same sums in the same order.
 __global__ void cheb_mix_kernel(const float *__restrict__ y, int ldy, int co, const float *__restrict__ tk,
                                 const float *__restrict__ bias, int leaky, float *__restrict__ out, int ldo) {
     __shared__ float sT[3 * 21 * 21];
     for (int i = threadIdx.x; i < 3 * 21 * 21; i += blockDim.x) sT[i] = tk[i];
     __syncthreads();
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, o = blockIdx.y * 32 + (threadIdx.x & 31);
+    if (o >= co) return;
     const float *yb = y + (size_t)b * 21 * ldy;
-    for (int idx = threadIdx.x; idx < 21 * co; idx += blockDim.x) {
-        const int i = idx / co, o = idx - i * co;
+    for (int i = threadIdx.x >> 5; i < 21; i += 8) {
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float part = 0.f;
+#pragma unroll
             for (int j = 0; j < 21; ++j) part += sT[(k * 21 + i) * 21 + j] * yb[(size_t)j * ldy + k * co + o];
             acc += part;
         }
@@ -745,7 +911,7 @@ __global__ void cheb_mix_kernel(const float *__restrict__ y, int ldy, int co, co
 }
 hipError_t launch_cheb_mix(const float *y, int ldy, int B, int co, const float *tk, const float *bias, int leaky,
                            float *out, int ldo, hipStream_t s) {
-    hipLaunchKernelGGL(cheb_mix_kernel, dim3(B), dim3(256), 0, s, y, ldy, co, tk, bias, leaky, out, ldo);
+    hipLaunchKernelGGL(cheb_mix_kernel, dim3(B, (co + 31) / 32), dim3(256), 0, s, y, ldy, co, tk, bias, leaky, out, ldo);
     return hipGetLastError();
 }
 
@@ -821,17 +987,9 @@ __device__ __forceinline__ void aa_span(int o, int in_size, float scale, float &
     count = min((int)(center + support + 0.5f), in_size) - first;
 }
 
-// OUT: 0 = NHWC4 fp32, 1 = NHWC8 fp16, 2 = split [hi8 | lo8] fp16 pairs (HMV_F32X3)
-template <int OUT>
-__global__ void frames_to_input_kernel(const uint8_t *__restrict__ frames, const int *__restrict__ boxes, int Hf, int Wf, int S_h,
-                                       int S_w, FrameNorm nm, void *__restrict__ out, size_t total) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) {
-        const int ox = (int)(i % S_w);
-        size_t t = i / S_w;
-        const int oy = (int)(t % S_h);
-        const size_t n = t / S_h;
+// one output pixel of the antialiased crop-resize + normalisation (datasets' transform, see hmv_forward_frames in handmv.h)
+__device__ __forceinline__ void frame_pixel(const uint8_t *__restrict__ frames, const int *__restrict__ boxes, size_t n, int oy, int ox,
+                                            int Hf, int Wf, int S_h, int S_w, const FrameNorm &nm, float &pr, float &pg, float &pb) {
         const int x1 = boxes[n * 4], y1 = boxes[n * 4 + 1], x2 = boxes[n * 4 + 2], y2 = boxes[n * 4 + 3];
         float acc[3] = {0.f, 0.f, 0.f};
         // windows wider than kMaxWindow px are treated like empty ones: a garbage box must not turn into an unbounded loop
@@ -869,8 +1027,24 @@ __global__ void frames_to_input_kernel(const uint8_t *__restrict__ frames, const
             const float k = 1.f / (wxsum * wysum * 255.f);
             acc[0] *= k; acc[1] *= k; acc[2] *= k;
         }
-        const float r = (acc[0] - nm.mean[0]) * nm.inv_std[0], g = (acc[1] - nm.mean[1]) * nm.inv_std[1],
-                    b = (acc[2] - nm.mean[2]) * nm.inv_std[2];
+        pr = (acc[0] - nm.mean[0]) * nm.inv_std[0];
+        pg = (acc[1] - nm.mean[1]) * nm.inv_std[1];
+        pb = (acc[2] - nm.mean[2]) * nm.inv_std[2];
+}
+
+// OUT: 0 = NHWC4 fp32, 1 = NHWC8 fp16, 2 = split [hi8 | lo8] fp16 pairs (HMV_F32X3)
+template <int OUT>
+__global__ void frames_to_input_kernel(const uint8_t *__restrict__ frames, const int *__restrict__ boxes, int Hf, int Wf, int S_h,
+                                       int S_w, FrameNorm nm, void *__restrict__ out, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int ox = (int)(i % S_w);
+        size_t t = i / S_w;
+        const int oy = (int)(t % S_h);
+        const size_t n = t / S_h;
+        float r, g, b;
+        frame_pixel(frames, boxes, n, oy, ox, Hf, Wf, S_h, S_w, nm, r, g, b);
         if (OUT == 2) {
             f16x8 hv = {0, 0, 0, 0, 0, 0, 0, 0}, lv = {0, 0, 0, 0, 0, 0, 0, 0};
             _Float16 a, c;
@@ -888,10 +1062,42 @@ __global__ void frames_to_input_kernel(const uint8_t *__restrict__ frames, const
         }
     }
 }
+// the same into the space-to-depth stem layout (nchw_to_s2d_kernel above): one thread per s2d pixel = 2 x 2 output pixels
+template <int MODE>
+__global__ void frames_to_s2d_kernel(const uint8_t *__restrict__ frames, const int *__restrict__ boxes, int Hf, int Wf, int S_h,
+                                     int S_w, int Hs, int Ws, FrameNorm nm, void *__restrict__ out, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int xs = (int)(i % Ws);
+        size_t t = i / Ws;
+        const int ys = (int)(t % Hs);
+        const size_t n = t / Hs;
+        float v[12];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int oy = 2 * ys + dy, ox = 2 * xs + dx, j = (dy * 2 + dx) * 3;
+                v[j] = v[j + 1] = v[j + 2] = 0.f;
+                if (oy < S_h && ox < S_w) frame_pixel(frames, boxes, n, oy, ox, Hf, Wf, S_h, S_w, nm, v[j], v[j + 1], v[j + 2]);
+            }
+        s2d_store<MODE>(out, i, v);
+    }
+}
 hipError_t launch_frames_to_input(const uint8_t *frames, const int *boxes, int N, int Hf, int Wf, int S_h, int S_w, const float *mean,
-                                  const float *std, int out_mode, void *out, hipStream_t s) {
+                                  const float *std, int out_mode, void *out, hipStream_t s, bool s2d) {
     FrameNorm nm;
     for (int c = 0; c < 3; ++c) { nm.mean[c] = mean[c]; nm.inv_std[c] = 1.f / std[c]; }
+    if (s2d) {
+        const int Hs = (S_h + 1) / 2, Ws = (S_w + 1) / 2;
+        const size_t total = (size_t)N * Hs * Ws;
+        const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+        if (out_mode == 2) hipLaunchKernelGGL(frames_to_s2d_kernel<2>, dim3(grid), dim3(256), 0, s, frames, boxes, Hf, Wf, S_h, S_w, Hs, Ws, nm, out, total);
+        else if (out_mode == 1) hipLaunchKernelGGL(frames_to_s2d_kernel<1>, dim3(grid), dim3(256), 0, s, frames, boxes, Hf, Wf, S_h, S_w, Hs, Ws, nm, out, total);
+        else hipLaunchKernelGGL(frames_to_s2d_kernel<0>, dim3(grid), dim3(256), 0, s, frames, boxes, Hf, Wf, S_h, S_w, Hs, Ws, nm, out, total);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)N * S_h * S_w;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (out_mode == 2) hipLaunchKernelGGL(frames_to_input_kernel<2>, dim3(grid), dim3(256), 0, s, frames, boxes, Hf, Wf, S_h, S_w, nm, out, total);

@@ -153,6 +153,12 @@ int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, int32_t N, 
                      const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
                      int32_t pad, const float *residual, int32_t relu, float *out, void *stream);
 
+/* One multi-head attention of the fusion transformer (layers.py:216-221; 8 heads x 128) through the engine's kernel
+ * (op-level parity tests).  qkv device [B][T][3 * 1024] = [q | k | v] per token; queries are tokens [0, Tq), keys / values
+ * tokens [koff, koff + Tk); out device [B][Tq][1024]. */
+int hmv_op_attention(int32_t device, const float *qkv, int32_t B, int32_t T, int32_t Tq, int32_t koff, int32_t Tk, float *out,
+                     void *stream);
+
 /* Diagnostic micro-benchmark: average milliseconds of `iters` launches of one NHWC conv shape on
  * pseudo-random data.  tile: -1 = the engine's own choice, else 0..7 = 128x32, 128x64, 128x128, 256x128,
  * 128x256, 256x256, 128x128 (k-step 16), 128x256 (k-step 16) (BM x BN).  HMV_BENCH_CLOCK=1 adds in-kernel clock stamps (stderr). */

@@ -396,7 +396,7 @@ def _random_case(seed):
     spec = dict(bt=bt, ch=ch, V=int(rng.integers(1, 6)), B=int(rng.integers(1, 4)), size=64, pos=pos, gcn=bool(rng.random() < 0.5),
                 wseed=1000 + seed, iseed=2000 + seed, fusion="cross_attn_learnable_query" if lq else "cross_attn",
                 fusion_layers=int([1, 3, 5][int(rng.integers(0, 3))]), freeze_bn=bool(rng.random() < 0.3))
-    hh, ww = [int(v) for v in rng.choice([64, 72, 88, 96, 100, 120], 2)]
+    hh, ww = [int(v) for v in rng.choice([64, 72, 77, 88, 96, 99, 100, 120], 2)]
     return spec, hh, ww
 
 
@@ -415,6 +415,8 @@ def test_random_configurations_match_oracle(seed):
     x = normalish("input.random", spec["iseed"], spec["B"] * spec["V"] * 3 * hh * ww).astype(np.float32).reshape(spec["B"], spec["V"], 3, hh, ww)
     m = HandMvNet(tp, mp, dp)
     m.load_state_dict(sd, strict=True)
+    if seed % 3 == 2:
+        m.float32x3()     # every third configuration on the split-precision kernels: the same fp32 bars
     got = _run(m, x, bbox, intr)
     ref = Oracle(cfg, sd, "f64").forward(x, bbox, intr, stages=True)
     assert got["heatmap"].shape == ref["heatmap"].shape == (spec["B"], spec["V"], 21) + tuple(heatmap_size_of(cfg, hh, ww))
@@ -423,3 +425,73 @@ def test_random_configurations_match_oracle(seed):
     print(seed, spec, (hh, ww), rep)
     assert rep["joints_cam"] <= TOL_CAM and rep["coords"] < 0.05, (spec, hh, ww, rep)
     assert max(rep["heatmap"], rep["feat0"], rep["tokens"], rep["fused"]) <= TOL_STAGE, (spec, hh, ww, rep)
+
+
+# (B, T, Tq, koff, Tk): self-attention over V * 21 tokens, the middle block's 21 queries against the rest, ragged key ranges
+ATTENTION_SHAPES = [(2, 21, 21, 0, 21), (3, 84, 84, 0, 84), (1, 168, 168, 0, 168), (2, 168, 21, 21, 147), (2, 84, 21, 21, 63),
+                    (1, 1008, 1008, 0, 1008), (2, 105, 21, 21, 84), (1, 33, 33, 0, 33), (1, 129, 129, 0, 129), (2, 64, 64, 0, 64)]
+
+
+@pytest.mark.parametrize("shape", ATTENTION_SHAPES)
+def test_attention_kernel_vs_torch(shape):
+    """op-level: the fusion transformer's attention (layers.py:216-221, 8 heads x 128) vs torch fp64 on the CPU; large
+    logits included (a softmax that is nearly one-hot) and the result must not depend on what else is in the batch."""
+    from handmvnet_amd import _lib
+    lib = _lib.load()
+    B, T, Tq, koff, Tk = shape
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = torch.randn(B, T, 3, 8, 128, generator=g)
+    qkv[:, :, 0] *= 3.0                                   # logits of std ~3 * sqrt(128) / sqrt(128): sharp rows
+    dev = torch.device("cuda:0")
+    qd = qkv.reshape(B, T, 3072).contiguous().to(dev)
+    out = torch.full((B, Tq, 1024), float("nan"), device=dev)
+    rc = lib.hmv_op_attention(0, qd.data_ptr(), B, T, Tq, koff, Tk, out.data_ptr(), None)
+    assert rc == 0, lib.hmv_last_error(None)
+    torch.cuda.synchronize()
+    q = qkv[:, :Tq, 0].double().permute(0, 2, 1, 3)       # [B, 8, Tq, 128]
+    k = qkv[:, koff:koff + Tk, 1].double().permute(0, 2, 1, 3)
+    v = qkv[:, koff:koff + Tk, 2].double().permute(0, 2, 1, 3)
+    att = torch.softmax(q @ k.transpose(-1, -2) * 128 ** -0.5, dim=-1) @ v
+    ref = att.permute(0, 2, 1, 3).reshape(B, Tq, 1024)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    # fp32 logits of magnitude ~12 carry ~1e-6 absolute rounding, which the exponential turns into ~1e-6 relative
+    assert (got - ref).abs().max().item() < 4e-6 * max(ref.abs().max().item(), 1.0)
+    # sample 0 alone gives the same bits
+    out1 = torch.full((1, Tq, 1024), float("nan"), device=dev)
+    rc = lib.hmv_op_attention(0, qd[:1].contiguous().data_ptr(), 1, T, Tq, koff, Tk, out1.data_ptr(), None)
+    assert rc == 0
+    assert torch.equal(out1[0], out[0])
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16", "f32x3"])
+def test_odd_frame_size_through_the_space_to_depth_stem(mode):
+    """The stem runs as a 4x4 conv over 2x2 space-to-depth frames; an odd H / W leaves a half-empty last row / column pair.
+    75 x 91 frames in every arithmetic mode against the f64 oracle (fp16: backbone features to the fp16-storage level --
+    a layout slip would be an O(1) error)."""
+    from cases import case_params
+    from handmvnet_amd import HandMvNet
+    from handmvnet_amd.spec import config_from_params
+    from handmvnet_amd.synth import normalish, synth_inputs, synth_state_dict
+    from oracle.oracle import Oracle
+    spec = dict(bt="18", ch=[256, 128, 64], V=2, B=2, size=64, pos=["pos2d", "crop", "sin"], gcn=True, wseed=77, iseed=78)
+    tp, mp, dp = case_params(spec)
+    cfg = config_from_params(tp, mp, dp)
+    sd = synth_state_dict(cfg, spec["wseed"])
+    hh, ww = 75, 91
+    _, bbox, intr = synth_inputs(cfg, spec["B"], spec["iseed"], 64)
+    x = normalish("input.odd", 5, spec["B"] * spec["V"] * 3 * hh * ww).astype(np.float32).reshape(spec["B"], spec["V"], 3, hh, ww)
+    m = HandMvNet(tp, mp, dp)
+    m.load_state_dict(sd, strict=True)
+    if mode == "f16":
+        m.half()
+    elif mode == "f32x3":
+        m.float32x3()
+    got = _run(m, x, bbox, intr)
+    ref = Oracle(cfg, sd, "f64").forward(x, bbox, intr, stages=True)
+    feat = rel_l2(got["feat0"], ref["feat0"])
+    print(mode, feat, rel_l2(got["joints_cam"], ref["joints_cam"]))
+    if mode == "f16":
+        assert feat <= 1e-2
+    else:
+        assert feat <= TOL_STAGE and rel_l2(got["joints_cam"], ref["joints_cam"]) <= TOL_CAM

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
     }
 
     // ---- XCD-aware tile assignment (bijective for any grid size)
-    int mt, nt, kslice_id = 0;
+    int mt, nt, kslice_id = 0, phase = 0;
     {
         const int nblk = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, r = nblk & 7;
@@ -211,9 +211,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
             kslice_id = lid % p.ksl;
             lid /= p.ksl;
         }
+        if constexpr (GENERIC) {
+            if (p.phases > 1) {   // sub-pixel phases of one tile: consecutive blocks as well (same input rows)
+                phase = lid % p.phases;
+                lid /= p.phases;
+            }
+        }
         mt = lid / p.ntiles;
         nt = lid - mt * p.ntiles;
     }
+    // The 4 sub-pixel phases (a, b) of a stride-2 transposed conv (k4 s2 p1 = four 2x2 convs) in ONE launch: phase = 2a + b has
+    // its own weight block, window origin (pad 1 - a, 1 - b) and output offset (a, b).  A small batch gives each phase only
+    // one workgroup per CU; together they are four, which hides the DMA latency of the short tiles.
+    const int pad_h = (GENERIC && p.phases > 1) ? 1 - (phase >> 1) : p.pad_h, pad_w = (GENERIC && p.phases > 1) ? 1 - (phase & 1) : p.pad_w;
+    const int ooy = (GENERIC && p.phases > 1) ? (phase >> 1) : p.ooy, oox = (GENERIC && p.phases > 1) ? (phase & 1) : p.oox;
+    const T *wgt_base = reinterpret_cast<const T *>(p.wgt) + (size_t)phase * p.phase_stride;
     const size_t koffs = (size_t)kslice_id * p.kslice;                          // this block's first reduction index
     char *outv = static_cast<char *>(p.out) + (size_t)kslice_id * p.out_slice * sizeof(float);
 
@@ -239,8 +251,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
         const int n = mm / HoWo, rem = mm - n * HoWo;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         const T *base = reinterpret_cast<const T *>(p.in) + koffs + (size_t)n * p.H * p.W * p.lda;
-        hi0[i] = ok ? ho * p.stride - p.pad_h : -(1 << 28);   // out-of-range rows fail every bounds test
-        wi0[i] = wo * p.stride - p.pad_w;
+        hi0[i] = ok ? ho * p.stride - pad_h : -(1 << 28);   // out-of-range rows fail every bounds test
+        wi0[i] = wo * p.stride - pad_w;
         if (MODE == MODE_1X1) {
             if (ok) { hi0[i] >>= p.up; wi0[i] >>= p.up; }   // nearest-neighbour upsampled input (HRNet fuse)
             aptr[i] = ok ? base + (hi0[i] * p.W + wi0[i]) * p.lda + koff : zero;
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
     const T *wptr[BP];
 #pragma unroll
     for (int i = 0; i < BP; ++i)
-        wptr[i] = reinterpret_cast<const T *>(p.wgt) + koffs + (size_t)(nt * BN + i * RPS + lrow) * p.ldw + EPC * kqs;
+        wptr[i] = wgt_base + koffs + (size_t)(nt * BN + i * RPS + lrow) * p.ldw + EPC * kqs;
 
     f32x16 acc[TM][TN];
     // 16-bit result rows (fp16 / (hi, lo) pairs): decides the channel order of the transposed-output accumulators (below)
@@ -804,7 +816,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
         auto out_row = [&](int m) -> size_t {   // sub-pixel scatter of the transposed convolution
             const int n = m / HoWo, rem = m - n * HoWo;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            return ((size_t)n * (p.Ho * p.osy) + (ho * p.osy + p.ooy)) * (size_t)(p.Wo * p.osx) + (wo * p.osx + p.oox);
+            return ((size_t)n * (p.Ho * p.osy) + (ho * p.osy + ooy)) * (size_t)(p.Wo * p.osx) + (wo * p.osx + oox);
         };
         if constexpr (RD) {
             // AS == TM: staged row == tile row.  One thread per 4 output channels of one pixel.
@@ -1163,7 +1175,7 @@ static hipError_t launch_one(ConvParams p, hipStream_t s) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.Cout + BN - 1) / BN;
     if (p.mtiles * p.ntiles < 4 * p.stagger_blocks) p.stagger = 0;   // too few rounds for a start-up offset to pay
-    hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles * (p.ksl > 1 ? p.ksl : 1)), dim3(64 * WGM * WGN), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles * (p.ksl > 1 ? p.ksl : 1) * (p.phases > 1 ? p.phases : 1)), dim3(64 * WGM * WGN), lds, s, p);
     return hipGetLastError();
 }
 
@@ -1213,6 +1225,8 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     if (HMV_TOUT && p.in_f16 && (p.out_f16 || p.out_split) &&
         (((p.out_split ? p.ldc >> 1 : p.ldc) & 7) || (p.res && ((p.res_split ? p.ldr >> 1 : p.ldr) & 7))))
         generic = true;
+    if (p.phases > 1 && (p.phases != 4 || !p.scatter || p.R != 2 || p.S != 2 || p.stride != 1 || p.ksl > 1 || p.in2 || p.rd_cout || p.phase_stride == 0))
+        return hipErrorInvalidValue;   // the merged launch exists for the four 2x2 phases of the k4 s2 p1 transposed conv only
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
     if (p.ksl > 1 && (!one || p.in_f16 || p.in2 || p.up || p.res || p.act != ACT_NONE || p.kslice <= 0 || p.kslice % 32 != 0 ||
                       p.ksl * p.kslice != p.Kpad || p.Cin % 32 != 0))

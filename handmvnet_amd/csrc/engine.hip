@@ -168,6 +168,8 @@ struct hmv_engine {
     std::vector<Block> blocks[3];
     Layer pose0, pose1, pose2;   // r50: pose0 (1x1 1024->512), pose1 (1x1 512->21); r18/34: pose1 (3x3 128->64), pose2 (3x3 64->21)
     Layer deconv[4];             // r18/34 ConvTranspose2d as 4 sub-pixel 2x2 convs (phase a*2+b)
+    Layer deconv_all;            // ... the same four with their weight blocks back to back (one launch); w == nullptr: not used
+    size_t deconv_stride = 0;    // elements between the phases' weight blocks
     Layer sample[4];
     std::vector<AttnLayer> attn;
     Layer gcn[3];
@@ -736,6 +738,25 @@ int hmv_finalize_weights(hmv_handle h) {
                     dl.Kreal = 4 * c0;
                     if (sp) dl.plane = c0;
                 }
+            // the four phases' weight blocks back to back: one launch runs all of them (conv_igemm.hip, p.phases).  Not in the
+            // split mode, whose per-layer power-of-two weight scale differs between the phases.
+            h->deconv_all = Layer();
+            if (!(L.split && h16) && !getenv("HMV_NO_PHASEMERGE") && L.rc == HMV_OK) {
+                const Layer &d0 = h->deconv[0];
+                const size_t elems = (size_t)d0.Cout_pad * d0.Kpad, bytes = elems * (h16 ? 2 : 4);
+                void *all = nullptr;
+                hipError_t e = hipMalloc(&all, 4 * bytes);
+                for (int i = 0; i < 4 && e == hipSuccess; ++i)
+                    e = hipMemcpy(static_cast<char *>(all) + i * bytes, h->deconv[i].w, bytes, hipMemcpyDeviceToDevice);
+                if (e != hipSuccess) L.rc = h->fail(HMV_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
+                if (all) h->dev_allocs.push_back(all);
+                if (e == hipSuccess) {
+                    h->deconv_all = d0;
+                    h->deconv_all.label = "pose_net.0";
+                    h->deconv_all.w = static_cast<float *>(all);
+                    h->deconv_stride = elems;
+                }
+            }
         }
         L.conv(h->pose1, "pose_net.3", "pose_net.3.weight", "pose_net.3.bias", "pose_net.4", 64, 128, 3, 3, 0, h16);
         L.conv(h->pose2, "pose_net.6", "pose_net.6.weight", "pose_net.6.bias", "", NJ, 64, 3, 3, 0, h16);
@@ -1010,6 +1031,8 @@ struct Runner {
 
     // One conv / GEMM launch.  in: NHWC [N][H][W][L.Cin] ; returns output dims through Ho/Wo.
     int ksplit = 1;   // split-K slices of the next conv() call (gemm() below)
+    int phases = 0;   // 4: the next conv() call runs the four transposed-conv phases in one launch (weights phase_stride apart)
+    size_t phase_stride = 0;
     // second A source of the next conv() call (conv3 + downsample as one GEMM); consumed by that call
     struct Dual { const float *in2 = nullptr; int ksplit = 0, H2 = 0, W2 = 0, lda2 = 0, stride2 = 1; } dual;
 
@@ -1028,6 +1051,7 @@ struct Runner {
         ConvParams p{};
         p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res; p.out = out;
         if (ksplit > 1) { p.ksl = ksplit; p.kslice = L.Kpad / ksplit; p.out_slice = (size_t)N * Ho * Wo * ldc; }
+        if (phases > 1) { p.phases = phases; p.phase_stride = phase_stride; }
         if (dual.in2) {
             p.in2 = dual.in2; p.ksplit = dual.ksplit; p.H2 = dual.H2; p.W2 = dual.W2; p.lda2 = dual.lda2; p.stride2 = dual.stride2;
             p.lda = dual.ksplit;   // the first source's pixel stride is its own channel count, not the concatenated one
@@ -1076,6 +1100,10 @@ struct Runner {
             const double in_px = (pointwise && stride > 1) ? (double)p.M : (double)N * H * W;
             pr->bytes = in_px * cin_real * eb_in + (double)L.Cout * kreal * eb_in + (double)p.M * cout_real * eb_out +
                         (res ? (double)p.M * cout_real * eb_in : 0.0);
+            if (phases > 1) {   // every phase: its own weights and output pixels, the same input
+                pr->flops *= phases;
+                pr->bytes = in_px * cin_real * eb_in + phases * ((double)L.Cout * kreal * eb_in + (double)p.M * cout_real * eb_out);
+            }
             if (dual.in2)   // [t2 | x]: t2 at every output pixel, x at the pixels the stride keeps
                 pr->bytes = ((double)p.M * dual.ksplit + (double)p.M * (kreal - dual.ksplit)) * eb_in + (double)L.Cout * kreal * eb_in +
                             (double)p.M * cout_real * eb_out;
@@ -1402,10 +1430,16 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     } else {
         hmh = 2 * fh; hmw = 2 * fw;
         float *p0 = R.alloc(ACT((size_t)N * hmh * hmw * 128));
-        for (int a = 0; a < 2; ++a)
-            for (int b = 0; b < 2; ++b)
-                R.conv(h->deconv[a * 2 + b], feat0, N, fh, fw, 1, 1 - a, 1 - b, p0, 128, nullptr, 0, ACT_RELU, fh, fw, 0, 0,
-                       /*scatter=*/1, a, b, h16);
+        if (h->deconv_all.w) {
+            R.phases = 4; R.phase_stride = h->deconv_stride;
+            R.conv(h->deconv_all, feat0, N, fh, fw, 1, 1, 1, p0, 128, nullptr, 0, ACT_RELU, fh, fw, 0, 0, /*scatter=*/1, 0, 0, h16);
+            R.phases = 0;
+        } else {
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b)
+                    R.conv(h->deconv[a * 2 + b], feat0, N, fh, fw, 1, 1 - a, 1 - b, p0, 128, nullptr, 0, ACT_RELU, fh, fw, 0, 0,
+                           /*scatter=*/1, a, b, h16);
+        }
         float *p1 = R.alloc(ACT((size_t)N * hmh * hmw * 64));
         R.conv(h->pose1, p0, N, hmh, hmw, 1, 1, 1, p1, 64, nullptr, 0, ACT_RELU, hmh, hmw, 0, 0, 0, 0, 0, h16);
         R.release(p0);

@@ -58,6 +58,8 @@ struct ConvParams {
     // reads in + s * kslice, wgt + s * kslice and writes its partial product to out + s * out_slice (floats); the caller adds them
     int ksl, kslice;
     size_t out_slice;
+    int phases;            // 4: the sub-pixel phases of a k4 s2 p1 transposed conv as ONE launch (generic epilogue, scatter)
+    size_t phase_stride;   // elements between the phases' packed weight blocks
     int burst;          // residual tile by one LDS-DMA burst per wave after the main loop (filled in by launch_conv)
     int prefetch;       // software L2 prefetch of the residual tile / later activation k-steps (filled in by launch_conv)
     int stagger;        // start-up stagger (filled in by launch_conv): the workgroups of the first dispatch round are split into 4

@@ -497,21 +497,22 @@ __global__ void layernorm_kernel(const float *__restrict__ x, int ldx, int rows,
 #pragma unroll
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
         const int c = lane + 64 * i;
+        if (64 * i >= d) { v[i] = 0.f; continue; }   // wave-uniform
+        const int cc = c < d ? c : 0;   // clamped: the loads are unconditional, so all of a row's loads are in flight together
         if (SK) {
+            float part[SK ? SK : 1];
+#pragma unroll
+            for (int k = 0; k < SK; ++k) part[k] = sk.slab[k * sk.slice + (size_t)row * sk.lds + cc];
+            const float bb = sk.bias[cc], rv = rr ? rr[cc] : 0.f;
             float t = 0.f;
-            if (c < d) {
-                float part[SK ? SK : 1];
 #pragma unroll
-                for (int k = 0; k < SK; ++k) part[k] = sk.slab[k * sk.slice + (size_t)row * sk.lds + c];   // independent loads
-                const float bb = sk.bias[c], rv = rr ? rr[c] : 0.f;
-#pragma unroll
-                for (int k = 0; k < SK; ++k) t += part[k];
-                t += bb;
-                if (rr) t += rv;
-            }
-            v[i] = t;
+            for (int k = 0; k < SK; ++k) t += part[k];
+            t += bb;
+            if (rr) t += rv;
+            v[i] = c < d ? t : 0.f;
         } else {
-            v[i] = c < d ? xr[c] : 0.f;
+            const float t = xr[cc];
+            v[i] = c < d ? t : 0.f;
         }
         s += v[i];
     }

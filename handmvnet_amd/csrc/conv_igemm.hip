@@ -111,8 +111,16 @@ constexpr int burst_blocks(int wave_bytes, int piece_count, int nblk) {
     while (cb > 1 && nblk % cb != 0) --cb;
     return cb;
 }
-constexpr int lds_floats(int BM, int BN, int WGM, int KB, bool full = false, bool staged = true) {
-    const int tile = 2 * (BM + BN) * KB;
+// Tile buffers in flight.  Two (double buffering) everywhere except the fp16 256x256 tile with a 32-element k-step
+// (TILE_256x256_RING): there FOUR 32 KB stages form a ring with three tiles in flight (96 KB instead of 64 KB, same 128 KB of
+// LDS).  Built in round 2 to test whether the ~2 us that a 64 KB k-step of the two-stage loop takes is one exposed L2 latency
+// per step.  It is not: with three tiles in flight the same convs run 4-8 % slower (twice the barriers), so the ~30 GB/s per
+// CU is a throughput limit of the L2 -> LDS path under chip-wide load, not latency.  Off by default (HMV_F16_RING=1).
+constexpr int ring_stages(bool f16, int KB, bool generic, bool rd, int BM, int BN) {
+    return (f16 && KB == 32 && !generic && !rd && BM == 256 && BN == 256) ? 4 : 2;
+}
+constexpr int lds_floats(int BM, int BN, int WGM, int KB, bool full = false, bool staged = true, int ns = 2) {
+    const int tile = ns * (BM + BN) * KB;
     if (!staged) return tile;   // register epilogue: the tile buffers are all the LDS a workgroup needs
     const int stage = WGM * stage_blocks(BM, BN, WGM, KB, full) * 32 * (BN + 4);
     return tile > stage ? tile : stage;
@@ -176,8 +184,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
     static_assert(TOUT || (TM % AS == 0 && SR * LDC <= lds_floats(BM, BN, WGM, KB4, RD)), "epilogue staging");
     static_assert(!RD || (!GENERIC && !PARTN), "row-decomposed epilogue");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    T *sA = reinterpret_cast<T *>(smem);   // [2][BM][KB]
-    T *sB = sA + 2 * BM * KB;              // [2][BN][KB]
+    constexpr int NS = ring_stages(F16, KB, GENERIC, RD, BM, BN);
+    static_assert(NS == 2 || (TOUT && !X3 && !PARTN), "ring main loop");
+    T *sA = reinterpret_cast<T *>(smem);   // [NS][BM][KB]
+    T *sB = sA + NS * BM * KB;             // [NS][BN][KB]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
         // this XCD's L2 right now, while the first operand tiles are on their way; the real accesses later hit L2.
         // Issued BEFORE the first DMA: loads return in order, so the waits below need no new counts.
         if (p.prefetch) {
-            float *sdummy = smem + 2 * (BM + BN) * KB4;
+            float *sdummy = smem + NS * (BM + BN) * KB4;
             if (p.res) {
                 constexpr int ebr = F16 ? 2 : 4;                       // residual element bytes (a split row holds two fp16 planes)
                 constexpr int lpr = (BN * ebr + 127) / 128;           // 128-byte lines per tile row and plane
@@ -462,12 +472,28 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
             }
         }
     }
-    HMV_DMA(0);
-    if (nk > 1) {
-        HMV_DMA(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");   // tile 0 landed, tile 1 may fly
+    // wait until at most `tiles_` of the DMAs issued so far are still in flight (loads retire in order; wave-uniform argument)
+#define HMV_WAIT_TILES(tiles_)                                                                              \
+    {                                                                                                       \
+        const int w_ = (tiles_);                                                                            \
+        if (w_ >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (AP + BP)) : "memory");                   \
+        else if (w_ == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AP + BP)) : "memory");              \
+        else if (w_ == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");                    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+    }
+    if constexpr (NS == 2) {
+        HMV_DMA(0);
+        if (nk > 1) {
+            HMV_DMA(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");   // tile 0 landed, tile 1 may fly
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_assert(NS == 2 || 3 * (AP + BP) < 64, "vmcnt range");
+        const int pre = nk < NS ? nk : NS;   // tiles 0 .. NS-1 go out together; tile 0 must have landed
+        for (int t = 0; t < pre; ++t) HMV_DMA(t);
+        HMV_WAIT_TILES(pre - 1);
     }
     asm volatile("s_barrier" ::: "memory");
     bool done = false;
@@ -509,22 +535,30 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
     if (!done) HMV_FRAGS(fa0, fb0, 0, 0);
 
     for (int kt = 0; !done && kt < nk; ++kt) {
-        const int buf = kt & 1;
+        const int buf = kt & (NS - 1);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {   // fragment sets alternate by the parity of q (NQ is even)
             if (q + 1 < NQ) {
                 if (q & 1) { HMV_FRAGS(fa0, fb0, buf, q + 1); } else { HMV_FRAGS(fa1, fb1, buf, q + 1); }
-            } else {
+            } else if constexpr (NS == 2) {
                 // tile kt+1 (the only DMA in flight) must have landed; everyone is done reading `buf`
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (kt + 2 < nk) HMV_DMA(buf);
                 if (kt + 1 < nk) HMV_FRAGS(fa0, fb0, buf ^ 1, 0);
+            } else {
+                // ring: tiles up to kt+NS-1 are out; tile kt+1 must have landed, kt+2 .. kt+NS-1 (as far as they exist) may fly
+                const int fly = nk - kt - 2;
+                HMV_WAIT_TILES(fly < 0 ? 0 : (fly > NS - 2 ? NS - 2 : fly));
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone is done reading `buf`
+                if (kt + NS < nk) HMV_DMA(buf);
+                if (kt + 1 < nk) HMV_FRAGS(fa0, fb0, (kt + 1) & (NS - 1), 0);
             }
             if (q & 1) { HMV_MFMA(fa1, fb1); } else { HMV_MFMA(fa0, fb0); }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 #undef HMV_DMA
+#undef HMV_WAIT_TILES
 #undef HMV_FRAGS
 #undef HMV_FRAG_A
 #undef HMV_FRAG_B
@@ -550,7 +584,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
         // (counted vmcnt: the stores issued meanwhile are younger than the DMAs they must not wait for) and read back with
         // one ds_read_b128 per piece (lane-linear image, conflict free).  Wave-private: no barrier.
         if (has_res && p.burst) {
-            constexpr int WLB = 2 * (BM + BN) * KB * (int)sizeof(T) / (NT / 64);   // bytes of tile buffer per wave
+            constexpr int WLB = NS * (BM + BN) * KB * (int)sizeof(T) / (NT / 64);   // bytes of tile buffer per wave
             char *wl = reinterpret_cast<char *>(smem) + wave * WLB;
             float *trash = const_cast<float *>(p.zero) + 64 + 4 * lane;   // 16 bytes per lane behind the zero page
             if constexpr (!F16) {
@@ -1083,14 +1117,14 @@ int conv_tile_bn(ConvTile t) {
     switch (t) {
         case TILE_128x32: return 32;
         case TILE_128x64: case TILE_64x64: return 64;
-        case TILE_128x256: case TILE_256x256: case TILE_128x256_K16: return 256;
+        case TILE_128x256: case TILE_256x256: case TILE_128x256_K16: case TILE_256x256_RING: return 256;
         default: return 128;
     }
 }
 
 // Family name = one rocprofv3 symbol: conv_igemm<T, BM, BN, WGM, WGN, MODE, false, KB>
 static const char *kTileShape[TILE_COUNT] = {"128x32", "128x64", "128x128", "256x128", "128x256", "256x256", "128x128,k16",
-                                              "128x256,k16", "256x128,k16", "64x64", "256x128,k16,w8"};
+                                              "128x256,k16", "256x128,k16", "64x64", "256x128,k16,w8", "256x256,ring"};
 static const char *tile_name(const char *dtype, ConvTile t, int mode, bool partn = false, bool rd = false) {
     static char names[2][TILE_COUNT][3][3][56];
     if (t < 0 || t >= TILE_COUNT || mode < 0 || mode > 2) return "conv_igemm<?>";
@@ -1111,7 +1145,7 @@ const char *conv_tile_name(ConvTile t, int mode) { return tile_name("f32", t, mo
 ConvTile conv_dense_tile(ConvTile t, bool f16) {
     switch (t) {
         case TILE_128x32: case TILE_128x64: case TILE_64x64: case TILE_256x128: return t;
-        case TILE_256x128_K16: case TILE_256x256: return TILE_256x128;
+        case TILE_256x128_K16: case TILE_256x256: case TILE_256x256_RING: return TILE_256x128;
         default: return TILE_128x128;
     }
 }
@@ -1162,7 +1196,8 @@ static hipError_t launch_one(ConvParams p, hipStream_t s) {
     }
     static bool configured[64] = {};   // per device ordinal
     constexpr bool tout = HMV_TOUT && sizeof(T) == 2 && !GENERIC && !RD;   // register epilogue: no staging memory (+ the 256-byte prefetch dummy slot)
-    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4, RD, !tout) * sizeof(float) + (tout ? 256 : 0);
+    constexpr int ns = ring_stages(sizeof(T) == 2, KB, GENERIC, RD, BM, BN);
+    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4, RD, !tout, ns) * sizeof(float) + (tout ? 256 : 0);
     auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD, X3>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -1234,14 +1269,14 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     if (p.in2 && (!one || p.stride != 1 || p.up || p.cwrap || p.x3_plane || p.rd_cout || p.ksplit <= 0 || p.ksplit >= p.K ||
                   p.ksplit % (p.in_f16 ? 64 : 32) != 0 || p.Cin % (p.in_f16 ? 64 : 32) != 0))
         return hipErrorInvalidValue;   // the second source exists in the chunked 1x1 mode only
-    if (generic && (tile == TILE_256x128 || tile == TILE_128x256 || tile == TILE_256x256 || tile == TILE_128x128_K16 || tile == TILE_256x128_K16W8 ||
+    if (generic && (tile == TILE_256x128 || tile == TILE_128x256 || tile == TILE_256x256 || tile == TILE_256x256_RING || tile == TILE_128x128_K16 || tile == TILE_256x128_K16W8 ||
                     tile == TILE_128x256_K16 || tile == TILE_256x128_K16))
         tile = TILE_128x128;   // the rarely used epilogue paths exist only for the 4-wave tiles
     const int ch = p.in_f16 ? 64 : 32, epc = p.in_f16 ? 8 : 4;
     const bool dense = p.Cin % ch != 0;
     // the fused split loop exists in the non-generic fp16 kernels with a 64-element k-step, chunked modes
     if (p.x3_plane && (!p.in_f16 || generic || p.rd_cout || p.cwrap || p.x3_plane % 8 != 0 || p.Cin != 2 * p.x3_plane ||
-                       (!dense && p.x3_plane % 32 != 0) || tile == TILE_128x128_K16 || tile == TILE_128x256_K16 || tile == TILE_256x128_K16))
+                       (!dense && p.x3_plane % 32 != 0) || tile == TILE_128x128_K16 || tile == TILE_128x256_K16 || tile == TILE_256x128_K16 || tile == TILE_256x256_RING))
         return hipErrorInvalidValue;
     // split operands: fp16 kernels only; the generic epilogue handles them on its vector path only
     if ((p.cwrap || p.res_split || p.out_split || p.acc_shift) &&
@@ -1276,6 +1311,12 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         if (p.up && (p.R != 1 || p.S != 1 || p.pad_h || p.pad_w || p.stride != 1)) return hipErrorInvalidValue;
         tile = conv_dense_tile(tile, p.in_f16 != 0);
     }
+    // fp16 256x256 (the plain kernels of the backbone) on the four-stage ring main loop (ring_stages above): measured 4-8 %
+    // SLOWER than the two-stage loop (profiles/r02_probe_ring.txt), so it stays behind a development knob
+    static int ring = -1;   // HMV_F16_RING=1 selects it (A/B runs)
+    if (ring < 0) { const char *e = getenv("HMV_F16_RING"); ring = e ? atoi(e) : 0; }
+    if (ring && p.in_f16 && tile == TILE_256x256 && !generic && !dense && !p.x3_plane && !p.cwrap && !p.rd_cout && p.ksl <= 1)
+        tile = TILE_256x256_RING;
     // last N-tile with >= 32 all-padding columns: the block-skipping instantiations (fp32, the three big tiles)
     const int mode = dense ? MODE_DENSE : (one ? MODE_1X1 : MODE_TAPS);
     static int no_skip = -1;   // development knob: HMV_NO_SKIPN=1 disables the block-skipping instantiations (A/B runs)
@@ -1325,6 +1366,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
             case TILE_256x128_K16: return launch_plain<_Float16, 256, 128, 4, 2, 32>(p, one, s);
             case TILE_128x256_K16: return launch_plain<_Float16, 128, 256, 2, 4, 32>(p, one, s);
             case TILE_256x256: return launch_plain<_Float16, 256, 256, 2, 4, 64>(p, one, s);
+            case TILE_256x256_RING: return launch_plain<_Float16, 256, 256, 2, 4, 32>(p, one, s);
             default: return hipErrorInvalidValue;
         }
     }

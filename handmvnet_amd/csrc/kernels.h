@@ -72,7 +72,8 @@ struct ConvParams {
 enum ConvTile { TILE_128x32 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x128 = 3, TILE_128x256 = 4, TILE_256x256 = 5,
                 TILE_128x128_K16 = 6, TILE_128x256_K16 = 7, TILE_256x128_K16 = 8, TILE_64x64 = 9,
                 TILE_256x128_K16W8 = 10,   // fp32: 8 waves, 64 accumulators per lane, 48 KB of tile buffers -> two workgroups per CU
-                TILE_COUNT = 11 };
+                TILE_256x256_RING = 11,    // fp16: 256x256, 32-element k-step, four 32 KB stages with three tiles in flight
+                TILE_COUNT = 12 };
 int conv_tile_bn(ConvTile t);                       // N-tile width of a tile config
 const char *conv_tile_name(ConvTile t, int mode);   // mode: 0 taps, 1 1x1/GEMM, 2 dense K (stem, Cin % 32 != 0)
 const char *conv_tile_name_f16(ConvTile t, int mode);

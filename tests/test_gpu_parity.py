@@ -397,10 +397,15 @@ def _random_case(seed):
                 wseed=1000 + seed, iseed=2000 + seed, fusion="cross_attn_learnable_query" if lq else "cross_attn",
                 fusion_layers=int([1, 3, 5][int(rng.integers(0, 3))]), freeze_bn=bool(rng.random() < 0.3))
     hh, ww = [int(v) for v in rng.choice([64, 72, 77, 88, 96, 99, 100, 120], 2)]
+    if seed >= 12:   # HRNet (fuse layers need frame sizes that are multiples of 32: hrnet.py:194-212), fewer levels kept too
+        bt = ["w40", "w64"][seed % 2]
+        full = [40, 80, 160, 320] if bt == "w40" else [64, 128, 256, 512]
+        spec.update(bt=bt, ch=full[:int(rng.integers(2, 5))], V=int(rng.integers(1, 4)), B=int(rng.integers(1, 3)))
+        hh, ww = [int(v) for v in rng.choice([64, 96, 128], 2)]
     return spec, hh, ww
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(16)))
 def test_random_configurations_match_oracle(seed):
     from cases import case_params
     from handmvnet_amd import HandMvNet
@@ -422,9 +427,15 @@ def test_random_configurations_match_oracle(seed):
     assert got["heatmap"].shape == ref["heatmap"].shape == (spec["B"], spec["V"], 21) + tuple(heatmap_size_of(cfg, hh, ww))
     rep = {k: rel_l2(got[k], ref[k]) for k in ("joints_cam", "heatmap", "feat0", "tokens", "fused")}
     rep["coords"] = float(np.abs(got["coords_hm"] - ref["coords_hm"]).max())
-    print(seed, spec, (hh, ww), rep)
-    assert rep["joints_cam"] <= TOL_CAM and rep["coords"] < 0.05, (spec, hh, ww, rep)
-    assert max(rep["heatmap"], rep["feat0"], rep["tokens"], rep["fused"]) <= TOL_STAGE, (spec, hh, ww, rep)
+    # conditioning: how far an fp32 CPU evaluation of the same graph (the oracle built as float) lands from the f64 one.  The
+    # learnable-query blocks have no LayerNorm; on some random weights their activations grow to ~450 and the softmax turns
+    # near-one-hot, where fp32 itself is only good to 1e-2 (profiles/r02_probe_lq_conditioning.txt).  The engine has to be as good as fp32 is there.
+    ref32 = Oracle(cfg, sd, "f32").forward(x, bbox, intr, stages=True)
+    cond = {k: rel_l2(ref32[k], ref[k]) for k in ("joints_cam", "fused")}
+    print(seed, spec, (hh, ww), rep, cond)
+    assert rep["joints_cam"] <= max(TOL_CAM, 4 * cond["joints_cam"]) and rep["coords"] < 0.05, (spec, hh, ww, rep, cond)
+    assert max(rep["heatmap"], rep["feat0"], rep["tokens"]) <= TOL_STAGE, (spec, hh, ww, rep)
+    assert rep["fused"] <= max(TOL_STAGE, 4 * cond["fused"]), (spec, hh, ww, rep, cond)
 
 
 # (B, T, Tq, koff, Tk): self-attention over V * 21 tokens, the middle block's 21 queries against the rest, ragged key ranges

@@ -89,3 +89,17 @@ def test_weight_loading_and_forward_state_machine():
         lib.hmv_destroy(h)
     assert lib.hmv_forward(None, 1, None, None, None, None, None, None, None) == ARG
     assert lib.hmv_version().startswith(b"handmv")
+
+
+def test_op_attention_argument_errors():
+    """hmv_op_attention (op-level test entry): ranges that would read outside [B][T][3072] are refused before any launch."""
+    import torch
+    from handmvnet_amd import _lib
+    lib = _lib.load()
+    qkv = torch.zeros(2, 42, 3072, device="cuda:0")
+    out = torch.zeros(2, 42, 1024, device="cuda:0")
+    ok = lib.hmv_op_attention(0, qkv.data_ptr(), 2, 42, 21, 21, 21, out.data_ptr(), None)
+    assert ok == 0
+    for args in ((2, 42, 43, 0, 42), (2, 42, 21, 30, 21), (2, 42, 21, 0, 0), (0, 42, 21, 0, 21), (2, 42, 0, 0, 21), (2, 42, 21, -1, 21)):
+        assert lib.hmv_op_attention(0, qkv.data_ptr(), *args, out.data_ptr(), None) != 0, args
+    assert lib.hmv_op_attention(0, None, 2, 42, 21, 0, 42, out.data_ptr(), None) != 0

@@ -86,6 +86,35 @@ def test_forward_frames_equals_forward_on_prepared_batch(name, mode):
     assert rel_l2(fused["heatmap"].cpu().numpy(), two_step["heatmap"].cpu().numpy()) < (5e-3 if half else 1e-4)
 
 
+@pytest.mark.parametrize("mode", ["f32", "f16", "f32x3"])
+def test_forward_frames_odd_output_size(mode):
+    """75 x 75 crops: the frame-preparation kernel writes the space-to-depth stem layout directly, and an odd size leaves a
+    half-empty last row / column pair that must read as zeros in every storage mode."""
+    from handmvnet_amd import HandMvNet
+    cfg, (tp, mp, dp), sd, (x, bbox, intr), fx = load_case("tiny_r18")
+    b, v, size = x.shape[0], x.shape[1], 75
+    rng = np.random.default_rng(23)
+    frames = rng.integers(0, 256, (b, v, 120, 160, 3), dtype=np.uint8)
+    frames = ((frames.astype(np.float32) + np.roll(frames, 1, 2) + np.roll(frames, 1, 3)) / 3).astype(np.uint8)
+    side = rng.integers(50, 140, (b, v))
+    x1, y1 = rng.integers(-20, 100, (b, v)), rng.integers(-20, 60, (b, v))
+    boxes = np.stack([x1, y1, x1 + side, y1 + side], axis=-1).astype(np.int32)
+    m = HandMvNet(tp, mp, dp)
+    m.load_state_dict(sd, strict=True)
+    m.to("cuda").eval()
+    if mode == "f16":
+        m.half()
+    elif mode == "f32x3":
+        m.float32x3()
+    cam = {"intrinsic": _dev(intr)}
+    two_step = m(_dev(fo.prepare_batch(frames, boxes, size)), _dev(boxes.astype(np.float32)), cam)
+    fused = m.forward_frames(_dev(frames), _dev(boxes), cam, image_size=size)
+    torch.cuda.synchronize()
+    half = mode == "f16"
+    assert rel_l2(fused["heatmap"].cpu().numpy(), two_step["heatmap"].cpu().numpy()) < (5e-3 if half else 1e-4)
+    assert rel_l2(fused["joints_cam"].cpu().numpy(), two_step["joints_cam"].cpu().numpy()) < (fp16_bounds("tiny_r18")["joints_cam"] if half else 1e-4)
+
+
 def test_prepare_frames_full_size_properties():
     """BASELINE-sized batch (256 frames of 480x640 -> 256x256): deterministic, every frame independent of its
     neighbours, output bounded by the normalised range of [0, 255]."""

@@ -88,10 +88,14 @@ static hipError_t ensure_zero_page(float **page) {
 // A-operand addressing modes
 enum { MODE_TAPS = 0,   // general R x S convolution, Cin % 32 == 0: the tap of a k-step is wave-uniform
        MODE_1X1 = 1,    // 1x1 / plain GEMM, no padding: one pointer bump per DMA, no bounds test
-       MODE_DENSE = 2   // any Cin % 4 == 0 (the stem on NHWC4 frames, HRNet's 40/80-channel branches): K is the plain
+       MODE_DENSE = 2,  // any Cin % 4 == 0 (the stem on NHWC4 frames, HRNet's 40/80-channel branches): K is the plain
                         // (r, s, c) order over the REAL channels, so no k is spent on channel padding; every 16-byte
                         // vector carries its own (tap, channel offset), derived per lane with two multiply-highs
+       MODE_HALO = 3    // 3x3 stride-1 pad-1 conv, fp16, 256-pixel tiles that are 16 x 16 BLOCKS of one image: per 64-channel
+                        // chunk the 18 x 18 halo of the block is fetched ONCE into LDS (41 KB) and the nine taps read it at
+                        // shifted rows, instead of nine 32 KB fetches of the shifted tile (MODE_TAPS); weights stream as before
 };
+constexpr int HALO_ROWS = 328;   // 18 * 18 = 324 halo pixels, padded to whole 8-row DMA pieces
 
 // Epilogue staging: per pass every wave stages AS of its 32-row accumulator blocks, so a pass holds
 // SR = WGM*AS*32 rows of BN+4 floats.  AS is the largest divisor of TM that fits the LDS budget
@@ -186,8 +190,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NS = ring_stages(F16, KB, GENERIC, RD, BM, BN);
     static_assert(NS == 2 || (TOUT && !X3 && !PARTN), "ring main loop");
-    T *sA = reinterpret_cast<T *>(smem);   // [NS][BM][KB]
-    T *sB = sA + NS * BM * KB;             // [NS][BN][KB]
+    constexpr bool HALO = MODE == MODE_HALO;
+    static_assert(!HALO || (TOUT && KB == 64 && BM == 256 && NS == 2 && !X3 && !PARTN && NT == 512), "halo mode");
+    T *sA = reinterpret_cast<T *>(smem);   // [NS][BM][KB]   (HALO: [2][HALO_ROWS][KB], one halo image per 64-channel chunk)
+    T *sB = sA + (HALO ? 2 * HALO_ROWS : NS * BM) * KB;   // [NS][BN][KB]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -253,8 +259,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
     const T *aptr[AP];
     int astep[AP], hi0[AP], wi0[AP];
     const int HoWo = p.Ho * p.Wo;
+    // HALO: tile mt = block (by, bx) of image n; this thread's halo rows r = 64 i + lrow <-> input pixel (16 by - 1 + r / 18,
+    // 16 bx - 1 + r % 18); pixels outside the image (and the 4 pad rows) come from the zero page
+    const T *hsrc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t hpix0 = 0;   // index of the block's first output pixel
+    if constexpr (HALO) {
+        const int tx = p.W >> 4, timg = (p.H >> 4) * tx;
+        const int n = mt / timg, trem = mt - n * timg, by = trem / tx, bx = trem - by * tx;
+        const T *img = reinterpret_cast<const T *>(p.in) + (size_t)n * p.H * p.W * p.lda + koff;
+        hpix0 = ((size_t)n * p.H + by * 16) * p.W + bx * 16;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
+        for (int i = 0; i < 6; ++i) {
+            const int r = 64 * i + lrow, hy = r / 18, hx = r - 18 * hy;
+            const int iy = by * 16 - 1 + hy, ix = bx * 16 - 1 + hx;
+            if (r < 324 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) hsrc[i] = img + ((size_t)iy * p.W + ix) * p.lda;
+        }
+    }
+#pragma unroll
+    for (int i = 0; HALO ? false : i < AP; ++i) {
         const int m = mt * BM + i * RPS + lrow;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
@@ -314,6 +336,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
         tnr = __builtin_amdgcn_readfirstlane(tnr < 0 ? 0 : (tnr > TN ? TN : tnr));
     }
     int cr = 0, cs = 0, cc = 0, cdelta = 0, ck = 0;   // load cursor (wave-uniform)
+    int dtap = 0, dchunk = 0;                          // HALO: (tap, 64-channel chunk) of the next tile the DMA cursor issues
     const int nk = (p.ksl > 1 ? p.kslice : p.Kpad) / KB;
 
     // issue the DMA of the cursor tile into LDS buffer `buf`, then advance the cursor
@@ -332,7 +355,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
             ss_ = (int)tap_ - sr_ * p.S;                                                                    \
             if (tap_ >= (unsigned)(p.R * p.S)) sr_ = 1 << 29;                                               \
         }                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                    \
+        if (HALO && dtap == 0) { /* first tap of a 64-channel chunk: its halo image, once */                \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                   \
+                if (i < 5 || wave == 0)                                                                     \
+                    HMV_GLDS16(hsrc[i] ? hsrc[i] + dchunk * CH : zero, sA + ((dchunk & 1) * HALO_ROWS + i * 64 + wave * 8) * KB); \
+        }                                                                                                   \
+        if (HALO) { if (++dtap == 9) { dtap = 0; ++dchunk; } }                                              \
+        _Pragma("unroll") for (int i = 0; HALO ? false : i < AP; ++i) {                                     \
             const T *src_;                                                                                  \
             if (MODE == MODE_1X1) {                                                                         \
                 src_ = aptr[i];                                                                             \
@@ -389,11 +418,28 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
     const int wl31 = (TOUT && out16) ? ((l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1)) : l31;
     const int fswb = LPR == 8 ? ((wl31 >> 1) & 7) : ((wl31 >> 2) & 3);
     const T *brow = sB + (wn * WN + wl31) * KB;
+    // HALO: the pixel operand of block a at tap (dy, dx) is halo row (py + dy) * 18 + px + dx of the chunk's halo image, with
+    // the swizzle of THAT row; (py, px) = the lane's pixel in the 16 x 16 block (block a = pixel rows 2a, 2a + 1 of the wave's
+    // WM / 16 rows).  hrow / hsw are set once per k-step (HMV_HALO_SET) for the step whose fragments are read next.
+    const T *hrow[TM];
+    int hsw[TM];
+    const int hbase = (wm * (WM / 16) + (l31 >> 4)) * 18 + (l31 & 15);
+#define HMV_HALO_SET(tap, chunk)                                                                            \
+    {                                                                                                       \
+        const int dy_ = (tap) / 3, toff_ = dy_ * 18 + ((tap) - 3 * dy_);                                    \
+        _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                    \
+            const int hr_ = hbase + 36 * a + toff_;                                                         \
+            hrow[a] = sA + (((chunk) & 1) * HALO_ROWS + hr_) * KB;                                          \
+            hsw[a] = (hr_ >> 1) & 7;                                                                        \
+        }                                                                                                   \
+    }
 #define HMV_FRAGS(FA, FB, buf, q)                                                                           \
     {                                                                                                       \
         const int ch_ = ((2 * (q) + kh) ^ fsw) * EPC;                                                       \
-        _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                      \
-            if (!PARTN || tnr > 0) FA[a] = *reinterpret_cast<const f32x4 *>(arow + ((buf) * BM + a * 32) * KB + ch_); \
+        _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                    \
+            if (HALO) FA[a] = *reinterpret_cast<const f32x4 *>(hrow[a] + ((2 * (q) + kh) ^ hsw[a]) * EPC);  \
+            else if (!PARTN || tnr > 0) FA[a] = *reinterpret_cast<const f32x4 *>(arow + ((buf) * BM + a * 32) * KB + ch_); \
+        }                                                                                                   \
         const int chb_ = ((2 * (q) + kh) ^ fswb) * EPC;                                                     \
         _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                      \
             if (!PARTN || b < tnr) FB[b] = *reinterpret_cast<const f32x4 *>(brow + ((buf) * BN + b * 32) * KB + chb_); \
@@ -440,7 +486,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
         // the tile buffers, never read) pulls (a) the residual tile and (b) the next k-steps of the activation rows into
         // this XCD's L2 right now, while the first operand tiles are on their way; the real accesses later hit L2.
         // Issued BEFORE the first DMA: loads return in order, so the waits below need no new counts.
-        if (p.prefetch) {
+        if (p.prefetch && !HALO) {
             float *sdummy = smem + NS * (BM + BN) * KB4;
             if (p.res) {
                 constexpr int ebr = F16 ? 2 : 4;                       // residual element bytes (a split row holds two fp16 planes)
@@ -485,7 +531,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
         HMV_DMA(0);
         if (nk > 1) {
             HMV_DMA(1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");   // tile 0 landed, tile 1 may fly
+            if constexpr (HALO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BP) : "memory");   // weights 0 and halo 0 landed, weights 1 may fly
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");   // tile 0 landed, tile 1 may fly
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -532,6 +579,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
             done = true;
         }
     }
+    int htap = 0, hchunk = 0;   // HALO: (tap, chunk) of the k-step whose fragments are read next
+    if constexpr (HALO) HMV_HALO_SET(0, 0);
     if (!done) HMV_FRAGS(fa0, fb0, 0, 0);
 
     for (int kt = 0; !done && kt < nk; ++kt) {
@@ -544,6 +593,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                 // tile kt+1 (the only DMA in flight) must have landed; everyone is done reading `buf`
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (kt + 2 < nk) HMV_DMA(buf);
+                if constexpr (HALO) {   // the next k-step: next tap of the same halo image, or tap 0 of the next chunk's
+                    if (++htap == 9) { htap = 0; ++hchunk; }
+                    HMV_HALO_SET(htap, hchunk);
+                }
                 if (kt + 1 < nk) HMV_FRAGS(fa0, fb0, buf ^ 1, 0);
             } else {
                 // ring: tiles up to kt+NS-1 are out; tile kt+1 must have landed, kt+2 .. kt+NS-1 (as far as they exist) may fly
@@ -559,6 +612,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
     }
 #undef HMV_DMA
 #undef HMV_WAIT_TILES
+#undef HMV_HALO_SET
 #undef HMV_FRAGS
 #undef HMV_FRAG_A
 #undef HMV_FRAG_B
@@ -712,6 +766,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
         // blocks are walked in the order g = a * TN + b; the residual of block g + PF is requested before block g is
         // finished (ring of PF + 1 register sets, indices static after unrolling)
         constexpr int PF = 1, RING = PF + 1;
+        // output row of tile row m: the row itself, or (HALO) pixel (l >> 4, l & 15) of the tile's 16 x 16 block
+        auto prow = [&](int m) -> size_t {
+            if constexpr (HALO) { const int l = m - mt * BM; return hpix0 + (size_t)(l >> 4) * p.W + (l & 15); }
+            else return (size_t)m;
+        };
         if (!out16) {
             const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 3) & ~3);
             f32x4 rv[RING][4];
@@ -743,7 +802,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                 if (g >= 0) {
                     const int a = g / TN, b = g % TN;
                     const int m = mrow0 + 32 * a;
-                    float *orow = reinterpret_cast<float *>(outv) + (size_t)m * p.ldc;
+                    float *orow = reinterpret_cast<float *>(outv) + prow(m) * p.ldc;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int col = nb0 + 32 * b + 8 * q + 4 * kh;
@@ -782,7 +841,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
                     if (g >= 0) {
                         const int a = g / TN, b = g % TN;
                         const int m = mrow0 + 32 * a;
-                        _Float16 *orow = reinterpret_cast<_Float16 *>(outv) + (size_t)m * p.ldc;
+                        _Float16 *orow = reinterpret_cast<_Float16 *>(outv) + prow(m) * p.ldc;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const int col = nb0 + 32 * b + 16 * j + 8 * kh;
@@ -1191,13 +1250,14 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
 
 template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false, bool X3 = false>
 static hipError_t launch_one(ConvParams p, hipStream_t s) {
-    if constexpr (!X3 && sizeof(T) == 2 && KB == 64 && !GENERIC && !PARTN && !RD) {
+    if constexpr (!X3 && sizeof(T) == 2 && KB == 64 && !GENERIC && !PARTN && !RD && MODE != MODE_HALO) {
         if (p.x3_plane) return launch_one<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD, true>(p, s);
     }
     static bool configured[64] = {};   // per device ordinal
     constexpr bool tout = HMV_TOUT && sizeof(T) == 2 && !GENERIC && !RD;   // register epilogue: no staging memory (+ the 256-byte prefetch dummy slot)
     constexpr int ns = ring_stages(sizeof(T) == 2, KB, GENERIC, RD, BM, BN);
-    const size_t lds = (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4, RD, !tout, ns) * sizeof(float) + (tout ? 256 : 0);
+    const size_t lds = MODE == MODE_HALO ? (size_t)2 * (HALO_ROWS + BN) * KB * sizeof(T) + 256   // two halo images + two weight stages
+                                         : (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4, RD, !tout, ns) * sizeof(float) + (tout ? 256 : 0);
     auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD, X3>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -1317,6 +1377,17 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     if (ring < 0) { const char *e = getenv("HMV_F16_RING"); ring = e ? atoi(e) : 0; }
     if (ring && p.in_f16 && tile == TILE_256x256 && !generic && !dense && !p.x3_plane && !p.cwrap && !p.rd_cout && p.ksl <= 1)
         tile = TILE_256x256_RING;
+    // fp16 3x3 stride-1 pad-1 convs on 256 x 256 tiles: 16 x 16 pixel blocks with the halo image in LDS (MODE_HALO)
+    static int halo = -1;   // development knob: HMV_NO_HALO=1 keeps the nine-fetch MODE_TAPS loop (A/B runs)
+    if (halo < 0) halo = getenv("HMV_NO_HALO") ? 0 : 1;
+    const bool use_halo = halo && p.in_f16 && tile == TILE_256x256 && !generic && !dense && !p.x3_plane && !p.cwrap && !p.rd_cout &&
+                          p.ksl <= 1 && !p.in2 && !p.res && !p.up && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad_h == 1 && p.pad_w == 1 &&
+                          p.Ho == p.H && p.Wo == p.W && p.H % 16 == 0 && p.W % 16 == 0 && p.Cin % 64 == 0 && p.lda == p.Cin &&
+                          p.M % 256 == 0;
+    if (use_halo) {
+        if (name) *name = "conv_igemm_f16<256x256,halo>";
+        return launch_one<_Float16, 256, 256, 2, 4, MODE_HALO, false, 64>(p, s);
+    }
     // last N-tile with >= 32 all-padding columns: the block-skipping instantiations (fp32, the three big tiles)
     const int mode = dense ? MODE_DENSE : (one ? MODE_1X1 : MODE_TAPS);
     static int no_skip = -1;   // development knob: HMV_NO_SKIPN=1 disables the block-skipping instantiations (A/B runs)

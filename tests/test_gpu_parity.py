@@ -194,6 +194,18 @@ def test_conv_kernel_fp16_vs_torch(shape):
     assert 1e-6 < err < 2e-3, err
 
 
+# 3x3 stride-1 convs large enough for the fp16 256x256 tile: 16 x 16 pixel blocks with the halo image in LDS (MODE_HALO);
+# one, two and three 64-channel chunks (the halo buffers alternate), a non-square map, image borders on every side
+HALO_SHAPES = [(32, 64, 64, 64, 256, 3, 1, 1, False, True), (32, 64, 64, 128, 256, 3, 1, 1, False, False),
+               (16, 32, 128, 192, 512, 3, 1, 1, False, True)]
+
+
+@pytest.mark.parametrize("shape", HALO_SHAPES)
+def test_conv_halo_tiles_fp16_vs_torch(shape):
+    err = _run_conv(shape, 1)
+    assert 1e-6 < err < 2e-3, err
+
+
 def _random_conv_shapes(n, seed):
     rng = np.random.default_rng(seed)
     shapes = []

@@ -1380,13 +1380,14 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     // fp16 3x3 stride-1 pad-1 convs on 256 x 256 tiles: 16 x 16 pixel blocks with the halo image in LDS (MODE_HALO)
     static int halo = -1;   // development knob: HMV_NO_HALO=1 keeps the nine-fetch MODE_TAPS loop (A/B runs)
     if (halo < 0) halo = getenv("HMV_NO_HALO") ? 0 : 1;
-    const bool use_halo = halo && p.in_f16 && tile == TILE_256x256 && !generic && !dense && !p.x3_plane && !p.cwrap && !p.rd_cout &&
+    const bool use_halo = halo && p.in_f16 && (tile == TILE_256x256 || tile == TILE_256x128) && !generic && !dense && !p.x3_plane && !p.cwrap && !p.rd_cout &&
                           p.ksl <= 1 && !p.in2 && !p.res && !p.up && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad_h == 1 && p.pad_w == 1 &&
                           p.Ho == p.H && p.Wo == p.W && p.H % 16 == 0 && p.W % 16 == 0 && p.Cin % 64 == 0 && p.lda == p.Cin &&
                           p.M % 256 == 0;
     if (use_halo) {
-        if (name) *name = "conv_igemm_f16<256x256,halo>";
-        return launch_one<_Float16, 256, 256, 2, 4, MODE_HALO, false, 64>(p, s);
+        if (name) *name = tile == TILE_256x256 ? "conv_igemm_f16<256x256,halo>" : "conv_igemm_f16<256x128,halo>";
+        return tile == TILE_256x256 ? launch_one<_Float16, 256, 256, 2, 4, MODE_HALO, false, 64>(p, s)
+                                    : launch_one<_Float16, 256, 128, 4, 2, MODE_HALO, false, 64>(p, s);
     }
     // last N-tile with >= 32 all-padding columns: the block-skipping instantiations (fp32, the three big tiles)
     const int mode = dense ? MODE_DENSE : (one ? MODE_1X1 : MODE_TAPS);

@@ -197,7 +197,7 @@ def test_conv_kernel_fp16_vs_torch(shape):
 # 3x3 stride-1 convs large enough for the fp16 256x256 tile: 16 x 16 pixel blocks with the halo image in LDS (MODE_HALO);
 # one, two and three 64-channel chunks (the halo buffers alternate), a non-square map, image borders on every side
 HALO_SHAPES = [(32, 64, 64, 64, 256, 3, 1, 1, False, True), (32, 64, 64, 128, 256, 3, 1, 1, False, False),
-               (16, 32, 128, 192, 512, 3, 1, 1, False, True)]
+               (16, 32, 128, 192, 512, 3, 1, 1, False, True), (64, 32, 32, 128, 128, 3, 1, 1, False, True)]   # the last: 256x128 tile
 
 
 @pytest.mark.parametrize("shape", HALO_SHAPES)

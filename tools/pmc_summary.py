@@ -30,12 +30,12 @@ def family(name: str) -> str:
         t = "f32" if m.group(1) == "float" else "f16"
         k16 = ",k16" if (t == "f32" and m.group(5) == "16") else ""
         skip = ",rowsum" if m.group(7) == "true" else (",skipN" if m.group(6) == "true" else "")
-        return f"conv_igemm_{t}<{m.group(2)}x{m.group(3)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense"}[m.group(4)] + skip + ">"
+        return f"conv_igemm_{t}<{m.group(2)}x{m.group(3)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense", "3": "halo"}[m.group(4)] + skip + ">"
     # rocprofv3 leaves the _Float16 instantiations mangled (DF16_): conv_igemm<_Float16, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD>
     m = re.match(r"_ZN3hmv10conv_igemmIDF16_Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)ELb[01]ELi(\d+)ELb[01]ELb([01])E", name)
     if m:
         k16 = ",k16" if m.group(4) == "32" else ""
-        return f"conv_igemm_f16<{m.group(1)}x{m.group(2)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense"}[m.group(3)] + \
+        return f"conv_igemm_f16<{m.group(1)}x{m.group(2)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense", "3": "halo"}[m.group(3)] + \
             (",rowsum" if m.group(5) == "1" else "") + ">"
     return re.sub(r"\(.*", "", name).replace("void ", "").replace("hmv::", "")
 

@@ -382,8 +382,17 @@ def main():
             got16 = m16(*probe)["joints_cam"].float().cpu().numpy()
             sec = {k: l2[k] for k in ("value", "unit", "ms_per_step", "dtype", "steps", "warmup", "roofline", "forward", "timed_region")}
             sec["joints_cam_rel_l2_vs_fp32_engine"] = float(f"{np.linalg.norm(got16 - ref32) / np.linalg.norm(ref32):.3e}")
-            sec["note"] = ("BASELINE configs[4]: conv stack in fp16 storage + fp16 MFMA, fp32 accumulation; tolerance and its derivation "
-                           "in DESIGN.md section 4 / tests/test_gpu_parity.py")
+            try:   # the fp16-STORAGE noise floor of this shape measured on the real reference (tests/golden/make_fp16_noise.py)
+                with open(os.path.join(ROOT, "tests", "golden", "fp16_noise.json")) as f:
+                    fl = json.load(f)["cases"]["cfg3s_r50_v8_256"]
+                sec["reference_fp16_storage_noise_floor"] = {"joints_cam_rel_l2": float(f"{fl['joints_cam_rel_l2']:.3e}"),
+                                                             "coord_flip_frac": float(f"{fl['coord_flip_frac']:.3e}")}
+            except (OSError, ValueError, KeyError):
+                pass
+            sec["note"] = ("BASELINE configs[4]: conv stack in fp16 storage + fp16 MFMA, fp32 accumulation.  Its error is that of fp16 "
+                           "STORAGE (x1000 soft-argmax flips near-tied heat-map peaks): the reference itself, with only its activations "
+                           "rounded to fp16, lands the noise floor above away from its fp32 run; tests hold the engine to 3x that floor "
+                           "(DESIGN.md section 4, tests/test_gpu_parity.py)")
             line["configs4_fp16"] = sec
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -41,6 +41,9 @@
 //   * MODE_DENSE: K = plain (r, s, c) over the REAL channels for Cin % 32 != 0 (stem, HRNet's 40 / 80-channel tensors).
 //   * PARTN ("skipN"): all-padding 32-column blocks of the last N tile are skipped (Cout = 80 / 160 / 320).
 //   * RD ("rowsum"): row-decomposed 3x3 conv for narrow outputs (3x1 GEMM with (s, cout) columns + row-sum epilogue).
+//   * MODE_HALO (fp16 3x3 stride-1 convs on 256-row tiles): the tile is a 16 x 16 pixel block, its 18 x 18 halo is fetched once
+//     per 64-channel chunk and the nine taps read it at shifted LDS rows (same K order and bits as MODE_TAPS, 43 % fewer bytes).
+//   * TILE_256x256_RING (fp16, 32-element k-step, four stages / three tiles in flight): a recorded negative result, off by default.
 //   * split operands (HMV_F32X3, fp16 kernels): fp32 values as (hi, lo) fp16 pairs, hi*hi + lo*hi + hi*lo; the fused loop
 //     issues the three products from one tile load (x3_plane), the cwrap loop walks hi, lo, hi as a 3x longer reduction.
 #include <cstdio>

@@ -510,7 +510,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
             if constexpr (MODE == MODE_1X1 && !X3) {
                 // activation rows: the LPR lanes that DMA one row take one further 128-byte line of it each (k-steps 2 ..)
                 constexpr int j0 = 2 * KB * (int)sizeof(T) / 128;
-                const int off = (j0 + tid % LPR) * 128, kbytes = p.Kpad * (int)sizeof(T);
+                // (a dual-source launch walks only ksplit channels of the first source's rows: never prefetch past them)
+                const int off = (j0 + tid % LPR) * 128, kbytes = (p.in2 ? p.ksplit : p.Kpad) * (int)sizeof(T);
 #pragma unroll
                 for (int i = 0; i < AP; ++i) {
                     const bool ok = astep[i] != 0 && off < kbytes && !p.cwrap;
@@ -1308,7 +1309,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         p.stagger = st_ticks;
         p.stagger_blocks = st_blocks;
         p.stagger_mode = st_mode;
-        static int pf = -1;   // development knob: HMV_PREFETCH=0 disables the software L2 prefetch (A/B runs)
+        static int pf = -1;   // development knob, OFF by default: HMV_PREFETCH=1 enables the software L2 prefetch (A/B runs)
         if (pf < 0) { const char *e = getenv("HMV_PREFETCH"); pf = e ? atoi(e) : 0; }
         p.prefetch = pf;
         static int burst = -1;   // development knob: HMV_BURST=0 keeps the residual on the register-ring path (A/B runs)
@@ -1326,6 +1327,8 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     if (p.phases > 1 && (p.phases != 4 || !p.scatter || p.R != 2 || p.S != 2 || p.stride != 1 || p.ksl > 1 || p.in2 || p.rd_cout || p.phase_stride == 0))
         return hipErrorInvalidValue;   // the merged launch exists for the four 2x2 phases of the k4 s2 p1 transposed conv only
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
+    // short-reduction residual 1x1 convs over many pixels (fp16 Bottleneck conv3): the persistent weight-stationary kernel
+    if (!generic && conv_stream_supported(p)) return launch_conv_stream(p, s, name);
     if (p.ksl > 1 && (!one || p.in_f16 || p.in2 || p.up || p.res || p.act != ACT_NONE || p.kslice <= 0 || p.kslice % 32 != 0 ||
                       p.ksl * p.kslice != p.Kpad || p.Cin % 32 != 0))
         return hipErrorInvalidValue;   // split-K: plain fp32 GEMM slices, epilogue left to the reduction kernel

@@ -1,0 +1,323 @@
+// conv_stream.hip -- persistent, weight-stationary 1x1 convolution for the fp16 path's HBM-bound layers.
+//
+// Replaces, for large pixel counts, the 1x1 convs of the Bottleneck whose reduction is short
+// (/root/reference/src/models/backbones/resnet.py:124-144: conv3 + bn3 + `out += residual` + relu with K = planes <= 256, and the
+// squeezing conv1 + bn1 + relu of layer1 / layer2):
+//
+//   out[m][n] = relu( sum_k A[m][k] * Wt[n][k] + bias[n] + res[m][n] )        fp16 rows in, fp32 accumulation, fp16 rows out
+//
+// Why a second kernel.  conv_igemm gives every 256 x 256 output tile its own workgroup: per tile it streams 128 KB of weights and
+// 128 KB of pixels through the CU's vector-memory pipe for 128 KB of residual and 128 KB of output, the three phases (operands,
+// residual burst, stores) run one after the other, and the next workgroup starts cold (~4 us).  These layers do 4-16 k-steps of
+// MFMA work per tile and are bound by that pipe (~25 GB/s per CU under chip-wide load): 3.2 TB/s of algorithmic bytes.
+//
+// MI355X mapping
+//   * ONE workgroup per CU for the whole launch (grid = 256).  A workgroup owns an N-slice (BN output channels) and walks the
+//     pixel tiles of its stream; the workgroups that own the other slices of the same pixel tiles sit on the same XCD and run in
+//     step, so a pixel tile leaves HBM once and is re-read from that XCD's L2.
+//   * the WEIGHTS LIVE IN REGISTERS for the whole launch: a wave keeps the MFMA A-operand fragments of its 32*TN channels for
+//     the full reduction (TN * K / 4 VGPRs: 128 for K = 256) -- no weight bytes move after the prologue, and no LDS is spent
+//     on them.  The 160 KB of LDS are all in-flight memory: a ring of pixel pieces ([BM pixels][64 channels] each, LDS-DMA,
+//     XOR-swizzled on the source side like conv_igemm) and two wave-private landing zones for the residual tiles.
+//   * one static instruction schedule per pixel tile, identical for every wave and every tile:
+//         piece step j:  wait(piece j landed) . barrier . DMA piece j + D . [j = 0: DMA the NEXT tile's residual] . MFMAs
+//         epilogue:      wait(residual landed) . acc + residual -> relu -> fp16 . 16-byte row stores
+//     so every wait is a COUNTED `s_waitcnt vmcnt(N)` whose N is a compile-time constant (vm_after_* below count the
+//     instructions issued since the awaited one); nothing in the loop ever drains the queue.  The next tile's pixels and
+//     residual (~90 KB) are in flight while this tile computes, drains and stores.  Rows past M and tiles past the stream's end
+//     read the zero page and store to the trash page, which keeps the counts exact; the prologue replays the schedule of the
+//     tiles "before the first" with the same dummies.
+//   * operand roles, accumulation order and epilogue arithmetic are those of conv_igemm's transposed-output path (weights as
+//     the MFMA A operand, bias as the accumulator's initial value, k ascending in 16-element blocks), so the results are
+//     BIT-IDENTICAL to conv_igemm's -- which keeps a sample's bits independent of the batch it is in, whichever kernel the
+//     launcher picks (tests/test_gpu_parity.py::test_stream_kernel_is_bit_identical).
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "kernels.h"
+
+namespace hmv {
+
+typedef float sf32x16 __attribute__((ext_vector_type(16)));
+typedef float sf32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
+
+#define HMV_SGLDS16(gptr, lptr)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// ---- the static schedule.  A pixel tile is NP + 1 slots: slot j < NP = piece step j (PA pixel DMAs, and at j = 0 the RB residual
+// DMAs of the next tile behind them), slot NP = the epilogue (OS stores).  vector-memory instructions retire in issue order, so
+// "X has landed" == "at most (instructions issued after X) are still out".
+constexpr int sched_ops(int NP, int PA, int RB, int OS, int slot) { return slot < NP ? PA + (slot == 0 ? RB : 0) : OS; }
+// instructions issued after the pixel DMAs of piece (t, j) when step (t, j) begins; they went out at step index g - D
+constexpr int sched_after_piece(int NP, int D, int PA, int RB, int OS, int j) {
+    const int T0 = 8, g = T0 * NP + j - D, tq = g / NP, jq = g - tq * NP;
+    int n = jq == 0 ? RB : 0;
+    for (int s = tq * (NP + 1) + jq + 1; s < T0 * (NP + 1) + j; ++s) n += sched_ops(NP, PA, RB, OS, s % (NP + 1));
+    return n;
+}
+// instructions issued after the residual DMAs of tile t (step (t - 1, 0)) when the epilogue of tile t begins
+constexpr int sched_after_residual(int NP, int PA, int RB, int OS) {
+    const int T0 = 8;
+    int n = 0;
+    for (int s = (T0 - 1) * (NP + 1) + 1; s < T0 * (NP + 1) + NP; ++s) n += sched_ops(NP, PA, RB, OS, s % (NP + 1));
+    return n;
+}
+static_assert(sched_after_piece(4, 3, 1, 8, 8, 0) == 10 && sched_after_piece(4, 3, 1, 8, 8, 1) == 18 && sched_after_piece(4, 3, 1, 8, 8, 2) == 18 &&
+              sched_after_piece(4, 3, 1, 8, 8, 3) == 10 && sched_after_residual(4, 1, 8, 8) == 23, "the K = 256 schedule, counted by hand");
+
+// TM x TN 32x32 blocks per wave, MW x NW waves (pixels x channels), NP 64-channel pieces of reduction, NSLOT ring slots.
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES>
+__global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(const ConvParams p) {
+    constexpr int NWV = MW * NW, NT = 64 * NWV;
+    constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW;
+    constexpr int D = NSLOT - 1;                 // pieces in flight ahead of the one being consumed
+    constexpr int PA = BM * 8 / NT;              // pixel DMA instructions per piece and thread (a piece row = 8 x 16 bytes)
+    constexpr int RB = HAS_RES ? TM * TN * 2 : 0, OS = TM * TN * 2;
+    constexpr int ZW = TM * TN * 2 * 1024;       // bytes of one wave's residual landing zone
+    constexpr int NFAKE = (D + NP - 1) / NP;     // tiles "before the first" whose schedule the prologue replays
+    static_assert(NT == 512 && BM % 64 == 0 && PA >= 1, "eight waves; whole DMA passes per piece");
+    static_assert((NP & (NP - 1)) == 0 && (NSLOT & (NSLOT - 1)) == 0 && NSLOT >= 2, "powers of two");
+    extern __shared__ __attribute__((aligned(16))) char ssm[];
+    _Float16 *sA = reinterpret_cast<_Float16 *>(ssm);            // [NSLOT][BM][64]
+    char *zones = ssm + NSLOT * BM * 128;                         // [2][NWV][ZW]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int mw = wave / NW, nw = wave - mw * NW;
+
+    // ---- stream assignment: the nsl slices of one pixel stream are workgroups of ONE XCD (blockIdx & 7), dispatched together
+    const int nsl = p.ntiles;                       // N-slices (Cout / BN), a divisor of 32
+    const int loc = (int)blockIdx.x >> 3, per_xcd = 32 / nsl;
+    const int slice = loc % nsl, stream = ((int)blockIdx.x & 7) * per_xcd + loc / nsl, nstreams = 8 * per_xcd;
+    const int ntl = p.mtiles > stream ? (p.mtiles - stream + nstreams - 1) / nstreams : 0;   // tiles of this workgroup
+    if (ntl == 0) return;
+    const int n0 = slice * BN + nw * TN * 32;       // this wave's first output channel
+
+    const _Float16 *zero16 = reinterpret_cast<const _Float16 *>(p.zero);
+    _Float16 *trash = reinterpret_cast<_Float16 *>(const_cast<float *>(p.zero) + 64 + 4 * lane);   // 16 bytes per lane, never read
+    const _Float16 *Ain = reinterpret_cast<const _Float16 *>(p.in);
+    const _Float16 *Rin = reinterpret_cast<const _Float16 *>(p.res);
+    _Float16 *Out = reinterpret_cast<_Float16 *>(p.out);
+
+    // ---- weights -> registers, once.  MFMA A operand of block b, k16 step Q: 8 halfs k = 16 Q + 8 kh .. + 7 of weight row
+    // swap23(l31) of the block (the row swap makes a lane's registers 8j .. 8j+7 eight CONSECUTIVE channels: conv_igemm TOUT)
+    const int wl31 = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    sf16x8 wreg[TN][NP * 4];
+    {
+        const _Float16 *wb = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(n0 + wl31) * p.ldw + 8 * kh;
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int Q = 0; Q < NP * 4; ++Q) wreg[b][Q] = *reinterpret_cast<const sf16x8 *>(wb + (size_t)(32 * b) * p.ldw + 16 * Q);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the counted waits below see only the schedule's own instructions
+
+    // pixel DMA role: thread -> (row arow of each 64-row pass, physical chunk tid & 7) fetching logical chunk kqs (XOR swizzle)
+    const int arow = tid >> 3, kqs = (tid & 7) ^ ((tid >> 4) & 7);
+    const int fsw = (l31 >> 1) & 7;
+
+    // issue the pixel DMAs of piece G (in this workgroup's own piece sequence; outside [0, ntl * NP) -> zero page)
+    auto issue_A = [&](int G) {
+        const int tt = G >= 0 ? G / NP : -1, jj = G & (NP - 1), slot = G & (NSLOT - 1);
+        const int mt = stream + tt * nstreams;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int m = mt * BM + i * 64 + arow;
+            const bool ok = tt >= 0 && tt < ntl && m < p.M;
+            const _Float16 *src = ok ? Ain + (size_t)m * p.lda + jj * 64 + 8 * kqs : zero16;
+            asm volatile("" : "+v"(src));   // ONE DMA instruction per schedule entry: keep the select out of the control flow
+            HMV_SGLDS16(src, sA + ((slot * BM + i * 64 + wave * 8) * 64));
+        }
+    };
+    // issue the residual DMAs of tile tt: every lane fetches ITS OWN 8 channels of its own pixel, lane-linear landing zone
+    auto issue_R = [&](int tt) {
+        if constexpr (HAS_RES) {
+            const int mt = stream + tt * nstreams;
+            char *z = zones + ((tt & 1) * NWV + wave) * ZW;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int m = mt * BM + (mw * TM + a) * 32 + l31;
+                const bool ok = tt >= 0 && tt < ntl && m < p.M;
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const _Float16 *src = ok ? Rin + (size_t)m * p.ldr + n0 + 32 * b + 16 * j + 8 * kh : zero16;
+                        asm volatile("" : "+v"(src));
+                        HMV_SGLDS16(src, z + ((a * TN + b) * 2 + j) * 1024);
+                    }
+            }
+        }
+    };
+
+    // ---- prologue: the schedule of the NFAKE tiles before the first, with every instruction it would have issued
+    // (real ones where they belong to tile 0 .., dummies otherwise), so that the counted waits hold from tile 0 on
+#pragma unroll
+    for (int ft = -NFAKE; ft < 0; ++ft) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            issue_A(ft * NP + j + D);
+            if (j == 0) issue_R(ft + 1);
+        }
+#pragma unroll
+        for (int i = 0; i < OS; ++i)   // inline asm: identical stores to one address must not be merged away
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(trash), "v"(sf32x4{0.f, 0.f, 0.f, 0.f}) : "memory");
+    }
+
+    const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    // wave-uniform address in the CONSTANT address space: the bias reads below are scalar (s_load) instructions -- a vector load
+    // here would enter the vmcnt queue and make the compiler drain it at every tile
+    const __attribute__((address_space(4))) float *bp0 =
+        (const __attribute__((address_space(4))) float *)(p.bias + __builtin_amdgcn_readfirstlane(n0));
+    sf32x16 acc[TM][TN];
+
+    for (int tt = 0; tt < ntl; ++tt) {
+        // bias = initial accumulator value: register 8j + u holds channel 16j + 8kh + u of the block.  Re-read (scalar cache) per
+        // tile behind an opaque zero offset: hoisted out of the loop the 16 * TN values would cost that many VGPRs for the launch
+        int bz;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(bz));
+        const __attribute__((address_space(4))) float *bp = bp0 + bz;
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = 32 * b + 16 * (e >> 3) + (e & 7);
+                const float v0 = bp[c], v1 = bp[c + 8];
+                const float v = kh ? v1 : v0;
+#pragma unroll
+                for (int a = 0; a < TM; ++a) acc[a][b][e] = v;
+            }
+        static_for<NP>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            wait_vm<sched_after_piece(NP, D, PA, RB, OS, j)>();                                       // my share of piece (tt, j) has landed
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // everyone's has; everyone is done with piece g - 1
+            issue_A(tt * NP + j + D);                                            // ... whose slot takes piece g + D
+            if constexpr (j == 0) issue_R(tt + 1);
+            const _Float16 *pa = sA + ((((tt * NP + j) & (NSLOT - 1)) * BM + mw * TM * 32 + l31) * 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sf16x8 px[TM];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) px[a] = *reinterpret_cast<const sf16x8 *>(pa + a * 32 * 64 + (((2 * q + kh) ^ fsw) * 8));
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[b][4 * j + q], px[a], acc[a][b], 0, 0, 0);
+            }
+        });
+        // ---- epilogue: acc (+ residual) -> relu -> fp16, 16-byte stores of 8 consecutive channels
+        if constexpr (HAS_RES) wait_vm<sched_after_residual(NP, PA, RB, OS)>();
+        const int mt = stream + tt * nstreams;
+        const char *z = zones + ((tt & 1) * NWV + wave) * ZW + lane * 16;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int m = mt * BM + (mw * TM + a) * 32 + l31;
+            _Float16 *orow = Out + (size_t)m * p.ldc + n0 + 8 * kh;
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    sf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if constexpr (HAS_RES) r = *reinterpret_cast<const sf16x8 *>(z + ((a * TN + b) * 2 + j) * 1024);
+                    sf16x8 hv;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + (float)r[u], lo);
+                    // every lane stores (the counts above rely on it): rows past M go to the trash page
+                    // one global store per schedule entry (a select spelled in C++ may become two exec-masked stores, and a pointer
+                    // made opaque loses its address space: flat stores retire out of order).  s_nop 1: the store must have read hv
+                    _Float16 *dst = m < p.M ? orow + 32 * b + 16 * j : trash;
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(hv) : "memory");
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+// ====================================================================== host side
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES>
+static hipError_t launch_stream_one(ConvParams p, hipStream_t s) {
+    constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW, NWV = MW * NW;
+    constexpr size_t lds = (size_t)NSLOT * BM * 128 + (HAS_RES ? (size_t)2 * NWV * TM * TN * 2 * 1024 : 0);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool configured[64] = {};
+    auto kern = conv_stream_f16<TM, TN, MW, NW, NP, NSLOT, HAS_RES>;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!configured[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[dev] = true;
+    }
+    p.mtiles = (p.M + BM - 1) / BM;
+    p.ntiles = p.Cout / BN;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(64 * NWV), lds, s, p);
+    return hipGetLastError();
+}
+
+// shapes with an instantiation: (K, BN) = (256, 512), (128, 512), (64, 256), residual-bearing (Bottleneck conv3)
+static int stream_bn(const ConvParams &p) {
+    if (p.Kpad == 256 || p.Kpad == 128) return 512;
+    if (p.Kpad == 64) return 256;
+    return 0;
+}
+
+// -1: the launcher's rule (HMV_NO_STREAM=1 in the environment disables the kernel for A/B runs); 0: never; 1: whenever the shape
+// has an instantiation, whatever the pixel count (op-level tests: hmv_op_conv2d_f16)
+static int g_stream_mode = -1;
+void conv_stream_set_mode(int mode) { g_stream_mode = mode; }
+
+bool conv_stream_supported(const ConvParams &p) {
+    static int off = -1;   // development knob: HMV_NO_STREAM=1 keeps every conv on conv_igemm (A/B runs)
+    if (off < 0) off = getenv("HMV_NO_STREAM") ? 1 : 0;
+    static int min_env = -1;   // tiles per workgroup below which the per-tile workgroups of conv_igemm fill the chip better
+    if (min_env < 0) { const char *e = getenv("HMV_STREAM_MIN_TILES"); min_env = e ? atoi(e) : 4; }
+    if (g_stream_mode == 0 || (g_stream_mode < 0 && off)) return false;
+    const int min_tiles = g_stream_mode > 0 ? 0 : min_env;
+    const int bn = stream_bn(p);
+    if (!bn || !p.in_f16 || !p.out_f16 || !p.res || !p.res_f16) return false;
+    if (p.R != 1 || p.S != 1 || p.stride != 1 || p.pad_h || p.pad_w || p.up || p.in2 || p.ksl > 1 || p.phases > 1) return false;
+    if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out || p.fill) return false;
+    if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
+    if (p.Cin != p.Kpad || p.K != p.Kpad || p.Cout % bn != 0 || 32 % (p.Cout / bn) != 0) return false;
+    if ((p.lda ? p.lda : p.Cin) % 8 || (p.ldw ? p.ldw : p.Kpad) % 8 || p.ldc % 8 || p.ldr % 8) return false;
+    const int bm = bn == 512 ? 64 : 128, streams = 256 / (p.Cout / bn);
+    return (long long)(p.M + bm - 1) / bm >= (long long)min_tiles * streams;
+}
+
+hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **name) {
+    if (p.Kpad == 256) {
+        if (name) *name = "conv_stream_f16<64x512,k256,res>";
+        return launch_stream_one<2, 2, 1, 8, 4, 4, true>(p, s);
+    }
+    if (p.Kpad == 128) {
+        if (name) *name = "conv_stream_f16<64x512,k128,res>";
+        return launch_stream_one<2, 2, 1, 8, 2, 4, true>(p, s);
+    }
+    if (p.Kpad == 64) {
+        if (name) *name = "conv_stream_f16<128x256,k64,res>";
+        return launch_stream_one<2, 2, 2, 4, 1, 2, true>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace hmv

@@ -1035,6 +1035,7 @@ struct Runner {
     size_t phase_stride = 0;
     // second A source of the next conv() call (conv3 + downsample as one GEMM); consumed by that call
     struct Dual { const float *in2 = nullptr; int ksplit = 0, H2 = 0, W2 = 0, lda2 = 0, stride2 = 1; } dual;
+    const char **kernel_name = nullptr;   // op-level entries: receives the kernel family of the last launch
 
     // Bottleneck conv3 + BN3 + downsample conv + BN + ReLU in one launch: out = relu([t2 | x(strided)] . Wcat + b)
     void conv_dual(const Layer &L, const float *t2, int planes, const float *x, int inpl, int N, int Hx, int Wx, int stride, float *out,
@@ -1111,6 +1112,7 @@ struct Runner {
         }
         const char *kname = nullptr;
         check(launch_conv(p, tile, s, &kname), L.label.c_str());
+        if (kernel_name) *kernel_name = kname;
         if (pr) {
             pr->name = kname;
             check(hipEventRecord(pr->e1, s), "hipEventRecord");
@@ -1528,6 +1530,10 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
             R.gemm(a.ff2, f1, qrows, Xn, ldt, o, ldt, ACT_NONE);          // out = ff(out) + out
             R.release(f1);
             R.release(o);
+            // The decoder's GEMM reads all ldt columns of the last block's output (its weights are zero there, but 0 * NaN is NaN)
+            // and no epilogue writes them: a GEMM epilogue stops at round4(d), the split-K reduction at d.  Inner blocks go
+            // through add_pe, which writes the pad itself.
+            if (l == 4 && ldt > d) LAUNCH(hipMemset2DAsync(Xn + d, (size_t)ldt * sizeof(float), 0, (size_t)(ldt - d) * sizeof(float), (size_t)qrows, s));
             X = Xn;
             Tcur = Tq;
         }
@@ -1792,6 +1798,16 @@ void hmv_destroy(hmv_handle h) {
     delete h;
 }
 
+/* Test hook: fills the workspace arena with the byte `value` (0xFF = NaNs).  Every stage must write what a later stage reads:
+ * a forward after poisoning must give the bits of a forward before it (tests/test_gpu_parity.py::test_poisoned_workspace). */
+int hmv_poison_workspace(hmv_handle h, int32_t value, void *stream) {
+    if (!h) return HMV_ERR_ARG;
+    if (!h->arena || !h->arena_bytes) return HMV_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemsetAsync(h->arena, value & 0xFF, h->arena_bytes, static_cast<hipStream_t>(stream)));
+    return HMV_OK;
+}
+
 int hmv_set_capture(hmv_handle h, int32_t enable) {
     if (!h) return HMV_ERR_ARG;
     h->capture = enable != 0;
@@ -1897,13 +1913,12 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
 }  // extern "C"
 
 // One conv in any arithmetic mode through the engine's own packing (Loader::conv) and launch path (Runner::conv).
-extern "C" int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
-                                const float *w_oihw, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
-                                int32_t pad, const float *residual, int32_t relu, float *out, void *stream) {
-    if (dtype == HMV_F32)
-        return hmv_op_conv2d(device, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad, residual, relu, out, stream);
-    if ((dtype != HMV_F16 && dtype != HMV_F32X3) || !in || !w_oihw || !out || Cin % 8 != 0 || Cout % 4 != 0) {
-        g_create_err = "hmv_op_conv2d_ex: dtype must be HMV_F32 / HMV_F16 / HMV_F32X3; the fp16-based modes need Cin % 8 == 0, Cout % 4 == 0";
+// out16: the layer writes fp16 rows (plain fp16 mode only), as every backbone layer of the fp16 path does
+static int op_conv2d_any(const char *who, int32_t device, int32_t dtype, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                         const float *w_oihw, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
+                         int32_t pad, const float *residual, int32_t relu, void *out, bool out16, const char **kernel_name, void *stream) {
+    if ((dtype != HMV_F16 && dtype != HMV_F32X3) || !in || !w_oihw || !out || Cin % 8 != 0 || Cout % 4 != 0 || (out16 && dtype != HMV_F16)) {
+        g_create_err = std::string(who) + ": dtype must be HMV_F32 / HMV_F16 / HMV_F32X3; the fp16-based modes need Cin % 8 == 0, Cout % 4 == 0";
         return HMV_ERR_ARG;
     }
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
@@ -1938,8 +1953,9 @@ extern "C" int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, 
         if (e == hipSuccess) {
             Arena dummy;
             Runner Rn{&eng, s, false, HMV_OK, dummy};
-            Rn.conv(layer, static_cast<const float *>(din), N, H, W, stride, pad, pad, out, Cout, static_cast<const float *>(dres), Cout,
-                    relu ? ACT_RELU : ACT_NONE, Ho, Wo);
+            Rn.kernel_name = kernel_name;
+            Rn.conv(layer, static_cast<const float *>(din), N, H, W, stride, pad, pad, static_cast<float *>(out), Cout,
+                    static_cast<const float *>(dres), Cout, relu ? ACT_RELU : ACT_NONE, Ho, Wo, 0, 0, 0, 0, 0, out16);
             rc = Rn.rc;
             if (rc == HMV_OK) e = hipStreamSynchronize(s);
         }
@@ -1947,7 +1963,28 @@ extern "C" int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, 
     if (din) (void)hipFree(din);
     if (dres) (void)hipFree(dres);
     for (void *ptr : eng.dev_allocs) (void)hipFree(ptr);
-    if (rc != HMV_OK) { g_create_err = "hmv_op_conv2d_ex: " + eng.err; return rc; }
-    if (e != hipSuccess) { g_create_err = std::string("hmv_op_conv2d_ex: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
+    if (rc != HMV_OK) { g_create_err = std::string(who) + ": " + eng.err; return rc; }
+    if (e != hipSuccess) { g_create_err = std::string(who) + ": " + hipGetErrorString(e); return HMV_ERR_HIP; }
     return HMV_OK;
+}
+
+extern "C" int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                                const float *w_oihw, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
+                                int32_t pad, const float *residual, int32_t relu, float *out, void *stream) {
+    if (dtype == HMV_F32)
+        return hmv_op_conv2d(device, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad, residual, relu, out, stream);
+    return op_conv2d_any("hmv_op_conv2d_ex", device, dtype, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad, residual, relu,
+                         out, false, nullptr, stream);
+}
+
+extern "C" int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *w_oihw,
+                                 const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad,
+                                 const float *residual, int32_t relu, void *out_f16, int32_t kernel_sel, const char **kernel_name,
+                                 void *stream) {
+    if (kernel_sel < 0 || kernel_sel > 2) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0, 1 or 2"; return HMV_ERR_ARG; }
+    conv_stream_set_mode(kernel_sel == 0 ? -1 : kernel_sel - 1);
+    const int rc = op_conv2d_any("hmv_op_conv2d_f16", device, HMV_F16, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad,
+                                 residual, relu, out_f16, true, kernel_name, stream);
+    conv_stream_set_mode(-1);
+    return rc;
 }

@@ -83,6 +83,11 @@ bool conv_partial_n(ConvTile t, int Cout);          // launch_conv uses the bloc
 // fills mtiles/ntiles and launches
 // `name` (optional) receives the kernel family actually launched ("conv_igemm_f32<256x128,dense,skipN>" ...)
 hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **name = nullptr);
+// conv_stream.hip: persistent weight-stationary 1x1 convolution (fp16 rows, residual-bearing, short reductions, many pixels);
+// launch_conv routes to it when conv_stream_supported(p).  Bit-identical to conv_igemm's result.
+bool conv_stream_supported(const ConvParams &p);
+void conv_stream_set_mode(int mode);   // -1 launcher's rule, 0 never, 1 whenever the shape has an instantiation (op-level tests)
+hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **name);
 
 // ---- small kernels
 hipError_t launch_nchw_to_nhwc4(const float *x, float *out, int N, int H, int W, hipStream_t s);

@@ -2,10 +2,10 @@
 
 Different multi-view samples are independent (the only cross-frame dependency is the
 fusion over the V views of ONE sample, handmvnet.py:225-227), so the path shards by sample
-with no data-path collective; the only communication is one all-gather of the results
+with no data-path collective; the only communication is ONE all-gather of the results per step
 (RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).  Payload per rank:
-joints_cam [B_local,21,3] + joints_crop_img [B_local,V,21,2] ~ 1.6 KB/sample -> latency
-bound; heat maps stay local.
+joints_cam [B_local,21,3] + joints_crop_img [B_local,V,21,2] packed into one row of
+63 + 42 V floats per sample (~1.6 KB/sample) -> latency bound; heat maps stay local.
 """
 from __future__ import annotations
 
@@ -13,6 +13,8 @@ from typing import Dict, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+KEYS = ("joints_cam", "joints_crop_img")
 
 
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -22,33 +24,75 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+class ResultGatherer:
+    """One packed all-gather per step.  Both result tensors of a rank travel as ONE [n_max, 63 + 42 V] fp32 block
+    (`joints_cam` | `joints_crop_img` per sample row); the send and receive buffers are allocated once, here, so a timed
+    loop allocates nothing and issues exactly one collective per step.  Ragged shards (total % world != 0, or fewer
+    samples than ranks) are padded to the largest shard: the collective has the same fixed size on every rank."""
+
+    def __init__(self, n_max: int, views: int, device, group=None, dtype=torch.float32):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_max, self.views = int(n_max), int(views)
+        self.row = 63 + 42 * self.views
+        self.send = torch.zeros((self.n_max, self.row), dtype=dtype, device=device)
+        self.recv = torch.empty((self.world * self.n_max, self.row), dtype=dtype, device=device)
+        self.collectives = 0   # all-gathers issued so far (the gloo test holds this to one per step)
+
+    def gather(self, local: Dict[str, torch.Tensor], total: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        cam, img = local["joints_cam"], local["joints_crop_img"]
+        n = cam.shape[0]
+        assert n <= self.n_max and img.shape[0] == n, "local shard larger than the gatherer was built for"
+        if n:
+            self.send[:n, :63].copy_(cam.reshape(n, 63))
+            self.send[:n, 63:].copy_(img.reshape(n, self.row - 63))
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        self.collectives += 1
+        blocks = self.recv.view(self.world, self.n_max, self.row)
+        if total is None or total == self.n_max * self.world:
+            full = blocks.reshape(self.world * self.n_max, self.row) if n == self.n_max else None
+            assert full is not None, "equal shards expected (pass total= for ragged ones)"
+        else:
+            spans = [shard_range(total, r, self.world) for r in range(self.world)]
+            assert spans[self.rank][1] - spans[self.rank][0] == n, "local shard does not match shard_range"
+            full = torch.cat([blocks[r, :b_ - a_] for r, (a_, b_) in enumerate(spans)], dim=0)
+        rows = full.shape[0]
+        return {"joints_cam": full[:, :63].reshape(rows, 21, 3), "joints_crop_img": full[:, 63:].reshape(rows, self.views, 21, 2)}
+
+
+_GATHERERS: Dict[tuple, ResultGatherer] = {}
+
+
+def gatherer_for(n_max: int, views: int, device, group=None) -> ResultGatherer:
+    """The cached ResultGatherer of this (group, shard size, views, device): buffers are allocated on first use only."""
+    key = (id(group), int(n_max), int(views), str(device))
+    g = _GATHERERS.get(key)
+    if g is None or g.world != dist.get_world_size(group):
+        g = _GATHERERS[key] = ResultGatherer(n_max, views, device, group)
+    return g
+
+
+def reset_gatherers() -> None:
+    """Drops the cached buffers (call after dist.destroy_process_group())."""
+    _GATHERERS.clear()
+
+
 def gather_outputs(local: Dict[str, torch.Tensor], total: Optional[int] = None, group=None,
-                   keys=("joints_cam", "joints_crop_img")) -> Dict[str, torch.Tensor]:
-    """All-gathers per-sample results along dim 0 in rank order.  `total` (global sample
-    count) is needed only for ragged shards; equal shards use one all_gather_into_tensor."""
+                   keys=KEYS) -> Dict[str, torch.Tensor]:
+    """All-gathers per-sample results along dim 0 in rank order with ONE collective.  `total` (global sample
+    count) is needed only for ragged shards."""
     if not (dist.is_available() and dist.is_initialized()):
         return {k: local[k] for k in keys}
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    out = {}
-    for k in keys:
-        t = local[k].contiguous()
-        n_local = t.shape[0]
-        if total is None or total == n_local * world:
-            full = torch.empty((n_local * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(full, t, group=group)
-        else:
-            # ragged shards: pad every shard to the largest one so that ONE fixed-size all-gather does
-            # (works on RCCL and gloo alike), then keep each rank's valid rows
-            spans = [shard_range(total, r, world) for r in range(world)]
-            assert spans[rank][1] - spans[rank][0] == n_local, "local shard does not match shard_range"
-            n_max = max(b_ - a_ for a_, b_ in spans)
-            padded = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            padded[:n_local] = t
-            buf = torch.empty((n_max * world,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(buf, padded, group=group)
-            full = torch.cat([buf[r * n_max:r * n_max + (b_ - a_)] for r, (a_, b_) in enumerate(spans)], dim=0)
-        out[k] = full
-    return out
+    world = dist.get_world_size(group)
+    n_local = local["joints_cam"].shape[0]
+    views = local["joints_crop_img"].shape[1]
+    if total is None or total == n_local * world:
+        n_max = n_local
+    else:
+        n_max = max(b_ - a_ for a_, b_ in (shard_range(total, r, world) for r in range(world)))
+    out = gatherer_for(n_max, views, local["joints_cam"].device, group).gather(local, total)
+    return {k: out[k] for k in keys}
 
 
 def forward_sharded(model, x: torch.Tensor, bbox=None, cam_params=None, group=None) -> Dict[str, torch.Tensor]:

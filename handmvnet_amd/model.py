@@ -337,6 +337,13 @@ class HandMvNet(torch.nn.Module):
         _lib.check(_lib.load().hmv_read_stage(h, name.encode(), out.data_ptr(), out.numel(), ctypes.c_void_p(stream)), h)
         return out
 
+    def poison_workspace(self, value: int = 0xFF):
+        """Test hook: fills the workspace of the engine the last forward ran on with `value` bytes (0xFF = NaN patterns)."""
+        hh, ww, idx, _, dt = self._last_key
+        h = self._engines[(hh, ww, idx, dt)]
+        stream = torch.cuda.current_stream(torch.device(f"cuda:{idx}")).cuda_stream
+        _lib.check(_lib.load().hmv_poison_workspace(h, int(value), ctypes.c_void_p(stream)), h)
+
     def use_graphs(self, enable: bool = True):
         """hipGraph replay of repeated forwards (opt-in, see include/handmv.h: hmv_set_graphs)."""
         self._graphs = bool(enable)

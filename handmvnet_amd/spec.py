@@ -93,6 +93,18 @@ def config_from_params(train_params: dict, model_params: dict, data_params: dict
     _ = data_params["batch_size"]
     layers = model_params.get("fusion_layers", 5)
     assert layers % 2 == 1, "num_layers must be an odd number"
+    if model_params["fusion"] == "cross_attn_learnable_query":
+        # An EXTENSION beyond the reference's runnable surface: HandMvNet.forward raises TypeError for this
+        # fusion (handmvnet.py:227 passes add_pos=, fusion.py:47 does not take it).  The module itself always has 5 blocks and adds
+        # its own positional encoding in every block, so two keys the reference reads have no effect here: say so.
+        ignored = []
+        if "sin" in model_params.get("pos_enc", ["pos2d", "sin"]):
+            ignored.append("'sin' in pos_enc (every learnable-query block adds its own PositionalEncoding, layers.py:273-275)")
+        if int(layers) != 5:
+            ignored.append(f"fusion_layers={layers} (CrossAttentionFusionLearnableQuery always builds 5 blocks, fusion.py:37-45)")
+        if ignored:
+            import warnings
+            warnings.warn("fusion='cross_attn_learnable_query' ignores " + " and ".join(ignored), stacklevel=2)
     if "num_views" in model_params:
         num_views = int(model_params["num_views"])
     else:  # config.py:46-49

@@ -100,6 +100,10 @@ size_t hmv_workspace_bytes(hmv_handle h, int32_t batch);
  * call it up front to keep allocation out of a timed or graph-captured region. */
 int hmv_reserve(hmv_handle h, int32_t batch);
 
+/* Test hook: fills the reserved workspace with the byte `value` (0xFF: NaNs) on `stream`.  No stage may read workspace bytes that
+ * an earlier stage of the SAME forward has not written, so a forward after poisoning returns the bits of one before it. */
+int hmv_poison_workspace(hmv_handle h, int32_t value, void *stream);
+
 /* Replaces HandMvNet.forward (handmvnet.py:158-266).  All pointers are DEVICE pointers.
  *   x               [B][V][3][H][W] fp32 (the reference's NCHW frames)
  *   bbox            [B][V][4]  (x1,y1,x2,y2), may be NULL unless HMV_POS_CROP
@@ -152,6 +156,14 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
 int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
                      const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
                      int32_t pad, const float *residual, int32_t relu, float *out, void *stream);
+
+/* The fp16-storage op with fp16 OUTPUT rows (what a backbone layer of the fp16 path writes): out_f16 device [N][Ho][Wo][Cout]
+ * halfs.  kernel_sel: 0 = the launcher's choice, 1 = conv_igemm only, 2 = the persistent weight-stationary kernel
+ * (conv_stream.hip) wherever the shape has an instantiation.  *kernel_name (optional) receives the family that ran. */
+int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                      const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
+                      int32_t pad, const float *residual, int32_t relu, void *out_f16, int32_t kernel_sel,
+                      const char **kernel_name, void *stream);
 
 /* One multi-head attention of the fusion transformer (layers.py:216-221; 8 heads x 128) through the engine's kernel
  * (op-level parity tests).  qkv device [B][T][3 * 1024] = [q | k | v] per token; queries are tokens [0, Tq), keys / values

@@ -109,6 +109,28 @@ def test_non_square_frames_match_oracle(name, mode):
         assert max(rep["heatmap"], rep["feat0"], rep["tokens"], rep["fused"]) <= TOL_STAGE, rep
 
 
+POISON_CASES = ["r50_lq", "r18_lq_wocam", "tiny_r50", "r18_frozen_nosin", "hr40_tiny", "r50_odd_96"]
+
+
+@pytest.mark.parametrize("name", [n for n in POISON_CASES if n in CASES])
+@pytest.mark.parametrize("mode", ["f32", "f16", "f32x3"])
+def test_poisoned_workspace(name, mode):
+    """No stage may read workspace bytes that an earlier stage of the same forward did not write (zero weights do not help:
+    0 * NaN = NaN).  The arena is filled with 0xFF bytes (NaN patterns in fp32 and fp16) between two forwards: the second one
+    must return the bits of the first.  Covers the pad columns [d, ldt) of the token matrices of both fusion modules."""
+    m, cfg, sd, (x, bbox, intr), _ = _model(name)
+    if mode == "f16":
+        m.half()
+    elif mode == "f32x3":
+        m.float32x3()
+    a = _run(m, x, bbox, intr, stages=False)
+    m.poison_workspace(0xFF)
+    b = _run(m, x, bbox, intr, stages=False)
+    for k in ("joints_cam", "joints_crop_img", "heatmap"):
+        assert np.isfinite(b[k]).all(), (name, mode, k)
+        assert np.array_equal(a[k], b[k]), (name, mode, k, float(np.abs(a[k] - b[k]).max()))
+
+
 CONV_SHAPES = [
     # N, H, W, Cin, Cout, k, stride, pad, residual, relu
     (2, 16, 16, 64, 64, 1, 1, 0, False, True),
@@ -204,6 +226,57 @@ HALO_SHAPES = [(32, 64, 64, 64, 256, 3, 1, 1, False, True), (32, 64, 64, 128, 25
 def test_conv_halo_tiles_fp16_vs_torch(shape):
     err = _run_conv(shape, 1)
     assert 1e-6 < err < 2e-3, err
+
+
+# 1x1 residual convs with the short reductions of Bottleneck conv3 (resnet.py:137-144), the shapes conv_stream.hip instantiates:
+# (K, channel slice) = (256, 512), (128, 512), (64, 256); pixel counts that are no multiple of the 64- / 128-pixel tiles, streams
+# with zero, one and several tiles, one to four channel slices
+STREAM_SHAPES = [(4, 32, 32, 256, 1024, 1, 1, 0, True, True), (3, 17, 19, 256, 512, 1, 1, 0, True, False),
+                 (64, 32, 32, 256, 1024, 1, 1, 0, True, True), (8, 32, 32, 128, 512, 1, 1, 0, True, True),
+                 (1, 33, 31, 128, 1024, 1, 1, 0, True, True), (40, 32, 32, 128, 512, 1, 1, 0, True, False),
+                 (4, 64, 64, 64, 256, 1, 1, 0, True, True), (2, 30, 35, 64, 512, 1, 1, 0, True, False),
+                 (40, 64, 64, 64, 256, 1, 1, 0, True, True)]
+
+
+def _run_conv_f16(shape, sel):
+    from handmvnet_amd import _lib
+    lib = _lib.load()
+    N, H, W, Cin, Cout, k, stride, pad, use_res, relu = shape
+    g = torch.Generator().manual_seed(sum(shape[:8]))
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, H, W, Cout, generator=g) if use_res else None
+    dev = torch.device("cuda:0")
+    xin = x.to(dev)
+    rdev = res.to(dev) if use_res else None
+    out = torch.full((N, H, W, Cout), float("nan"), device=dev, dtype=torch.float16)
+    wc, bc = w.contiguous().numpy(), b.contiguous().numpy()
+    kname = ctypes.c_char_p()
+    rc = lib.hmv_op_conv2d_f16(0, xin.data_ptr(), N, H, W, Cin, wc.ctypes.data_as(ctypes.c_void_p), bc.ctypes.data_as(ctypes.c_void_p),
+                               Cout, k, k, stride, pad, rdev.data_ptr() if use_res else None, int(relu), out.data_ptr(), sel,
+                               ctypes.byref(kname), None)
+    assert rc == 0, lib.hmv_last_error(None)
+    return out.cpu(), kname.value.decode(), (x, w, b, res, relu)
+
+
+@pytest.mark.parametrize("shape", STREAM_SHAPES)
+def test_stream_kernel_is_bit_identical(shape):
+    """The persistent weight-stationary kernel against conv_igemm on the same operands: same bits (it keeps conv_igemm's operand
+    roles, accumulation order and epilogue arithmetic -- which is what makes a sample's result independent of the batch whichever
+    kernel the launcher picks), and both against torch fp64 at fp16 accuracy."""
+    a, ka, (x, w, b, res, relu) = _run_conv_f16(shape, 2)
+    c, kc, _ = _run_conv_f16(shape, 1)
+    assert ka.startswith("conv_stream_f16") and kc.startswith("conv_igemm_f16"), (ka, kc)
+    assert torch.isfinite(a.float()).all()
+    assert torch.equal(a.view(torch.int16), c.view(torch.int16)), (ka, kc, (a.float() - c.float()).abs().max())
+    if shape[0] * shape[1] * shape[2] <= 8192:   # fp64 reference on the CPU for the small cases
+        xh, wh, rh = x.half().double(), w.half().double(), res.half().double()
+        ref = torch.einsum("nhwc,oc->nhwo", xh, wh[:, :, 0, 0]) + b.double() + rh
+        if relu:
+            ref = ref.clamp_min(0)
+        err = (a.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-3, err
 
 
 def _random_conv_shapes(n, seed):
@@ -340,7 +413,7 @@ def test_state_dict_errors_match_reference_behaviour():
 # in layer1/2 already, so a mixed-precision tail is not a remedy and is not built.  The engine is held to:
 #   * heat map:           <= 2 x the floor's rel-L2 (+ 2e-4)
 #   * coordinates:        median <= 0.02 px; fraction moved by > 1/2 px <= floor + 2 %
-#   * joints_cam:         <= 3 x the floor's rel-L2 (+ 2e-3)
+#   * joints_cam:         <= min(3 x the floor's rel-L2, max(0.15, 1.5 x the floor)) (+ 2e-3)
 # i.e. "as close to the fp32 reference as fp16 storage lets ANY implementation be, within a small factor".  The
 # fp32-grade alternative on the same matrix cores is HMV_F32X3 (next test), which meets the fp32 bars.
 # ---------------------------------------------------------------------------------------------
@@ -350,8 +423,11 @@ with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp
 
 def fp16_bounds(name):
     fl = FP16_NOISE[name]
+    # joints_cam: 3 x the floor where the floor is small; capped at max(0.15, 1.5 x floor) so that a large floor (random-weight
+    # fusion amplifying soft-argmax flips) cannot turn the factor 3 into room for a 30 % pose error
+    cam = fl["joints_cam_rel_l2"]
     return {"heatmap": 2.0 * fl["heatmap_rel_l2"] + 2e-4, "flip": fl["coord_flip_frac"] + 0.02,
-            "joints_cam": 3.0 * fl["joints_cam_rel_l2"] + 2e-3}
+            "joints_cam": min(3.0 * cam + 2e-3, max(0.15, 1.5 * cam + 2e-3))}
 
 
 @pytest.mark.parametrize("name", list(CASES))

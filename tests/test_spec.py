@@ -121,3 +121,17 @@ def test_state_dict_follows_the_nn_module_protocol():
     del bad["model.pose_net.0.bias"]
     with pytest.raises(RuntimeError, match="model.pose_net.0.bias"):
         p.load_state_dict(bad, strict=True)
+
+
+def test_learnable_query_fusion_warns_about_keys_it_ignores():
+    """cross_attn_learnable_query is an extension beyond the reference's runnable surface (handmvnet.py:227 raises TypeError): the
+    module always has 5 blocks and its own per-block PE, so 'sin' in pos_enc / fusion_layers != 5 have no effect -- and say so."""
+    tp, mp, dp = case_params(CASES["r50_lq"])
+    mp = dict(mp, pos_enc=["pos2d", "crop", "sin"], fusion_layers=3)
+    with pytest.warns(UserWarning, match="ignores .*'sin' in pos_enc.* and fusion_layers=3"):
+        cfg = S.config_from_params(tp, mp, dp)
+    assert cfg.learnable_query
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        S.config_from_params(tp, dict(mp, pos_enc=["pos2d", "crop"], fusion_layers=5), dp)

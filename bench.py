@@ -30,7 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from handmvnet_amd import HandMvNet  # noqa: E402
-from handmvnet_amd.dist import gather_outputs  # noqa: E402
+from handmvnet_amd.dist import gatherer_for  # noqa: E402
 from handmvnet_amd.spec import config_from_params, conv_flops_per_image  # noqa: E402
 from handmvnet_amd.synth import synth_inputs, synth_state_dict  # noqa: E402
 
@@ -40,16 +40,18 @@ PEAK_HBM_GBS = 8000.0          # same guide, "HBM3E peak BW 8.0 TB/s spec" (6.29
 
 WORKLOADS = {
     # name: (backbone_type, channels, V, B per GPU, size)
+    "cfg1": ("50_paper", [1024], 4, 1, 128),       # BASELINE.json configs[0]: HO3D_HandMvNet.yaml, batch 1, 4 views, 128x128 (its CPU plumbing case)
     "cfg3": ("50_paper", [1024], 8, 32, 256),      # BASELINE.json configs[2]
     "cfg2": ("18", [256, 128, 64], 4, 8, 256),     # BASELINE.json configs[1]
     "hr40": ("w40", [40, 80, 160, 320], 8, 32, 256),   # the *_HR release configs' backbone at the headline shape
 }
 
 
-def params(bt, ch, V, B, size):
+def params(bt, ch, V, B, size, fusion="cross_attn"):
     tp = {"debug": False, "root_relative": True}
+    lq = fusion == "cross_attn_learnable_query"   # (its blocks add their own PE: no 'sin' in pos_enc, spec.py warns otherwise)
     mp = {"num_views": V, "backbone": "hrnet" if bt.startswith("w") else "resnet", "backbone_type": bt, "backbone_channels": ch, "backbone_pretrained": False,
-          "backbone_early_return": 3, "pos_enc": ["pos2d", "crop", "sin"], "fusion": "cross_attn", "fusion_layers": 5,
+          "backbone_early_return": 3, "pos_enc": ["pos2d", "crop"] if lq else ["pos2d", "crop", "sin"], "fusion": fusion, "fusion_layers": 5,
           "use_gcn": True}
     dp = {"batch_size": B, "image_size": size, "heatmap_size": size // 8, "name": "dexycb"}
     return tp, mp, dp
@@ -69,6 +71,25 @@ def forward_flops(cfg, B, size):
     fusion = half * block(T, T) + block(21, T - 21) + half * block(21, 21)
     dec = 2 * 21 * 3 * (d * 256 + 256 * 64 + 64 * 3)
     return B * (V * per_frame + fusion + dec)
+
+
+def forward_block(dtype, total_flops, ms_step, fam, n_instr):
+    """Whole-forward figures.  fp32: dense algorithmic TFLOP/s against the fp32 MFMA peak (the north-star fraction).  fp16 /
+    f32x3: the step's own floors -- MFMA time of the algorithmic FLOPs at the fp16 peak (x3 executed for f32x3) and HBM time of
+    the algorithmic bytes of every conv / GEMM launch at 8 TB/s -- and the step time as a fraction of the higher one."""
+    tf = total_flops / (ms_step * 1e-3) / 1e12
+    fwd = {"algorithmic_gflop": round(total_flops / 1e9, 1), "tflops": round(tf, 2)}
+    if dtype == "f32":
+        fwd["frac_of_f32_mfma_peak"] = round(tf / PEAK_F32_MFMA_TFLOPS, 4)
+        return fwd
+    bytes_step = sum(v["bytes"] for v in fam.values()) / max(n_instr, 1)
+    t_mfma = (3.0 if dtype == "f32x3" else 1.0) * total_flops / (PEAK_F16_MFMA_TFLOPS * 1e12) * 1e3
+    t_hbm = bytes_step / (PEAK_HBM_GBS * 1e9) * 1e3
+    per_launch = sum(max(v["t_hbm"], v["t_mfma"]) for v in fam.values()) / max(n_instr, 1) * 1e3
+    fwd["algorithmic_gbytes"] = round(bytes_step / 1e9, 2)
+    fwd["step_floor_ms"] = {"mfma": round(t_mfma, 3), "hbm@8TB/s": round(t_hbm, 3), "sum_of_per_launch_floors": round(per_launch, 3)}
+    fwd["frac_of_step_floor"] = round(max(t_mfma, t_hbm) / ms_step, 4)
+    return fwd
 
 
 def cpu_baseline(cfg, sd, size, model, dev, min_seconds=10.0):
@@ -161,7 +182,7 @@ def measure(args, world, rank, dev):
     bt, ch, V, B, size = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
-    tp, mp, dp = params(bt, ch, V, B, size)
+    tp, mp, dp = params(bt, ch, V, B, size, args.fusion)
     cfg = config_from_params(tp, mp, dp)
     sd = synth_state_dict(cfg, 1)
     model = HandMvNet(tp, mp, dp)
@@ -186,9 +207,12 @@ def measure(args, world, rank, dev):
         org = torch.randint(-40, 300, (B, V, 2), device=dev, generator=g)
         crop_boxes = torch.cat([org, org + side], dim=-1).int()
 
+    # one packed all-gather of (joints_cam | joints_crop_img) per step; its buffers exist before the timed loop
+    gat = gatherer_for(B, V, dev) if world > 1 else None
+
     def step():
         out = model.forward_frames(raw, crop_boxes, cam, image_size=size) if args.input == "frames" else model(xt, bt_, cam)
-        return gather_outputs(out) if world > 1 else out
+        return gat.gather(out) if gat is not None else out
 
     for _ in range(args.warmup):
         step()
@@ -223,7 +247,18 @@ def measure(args, world, rank, dev):
         n_instr = args.steps
     recs = model.profile_records()
     model.set_profiling(False)
+    launches = model.launch_count()
+    # what the communicator itself saw: its size, and from every rank its device and its own clock over the timed steps
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "device": str(dev), "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+            "pci_bus_id": int(getattr(props, "pci_bus_id", -1)), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "collectives": gat.collectives if gat is not None else 0}
+    ranks = [mine]
+    ranks_seen = 1
     if world > 1:
+        ranks_seen = dist.get_world_size()
+        ranks = [None] * ranks_seen
+        dist.all_gather_object(ranks, mine)
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -284,24 +319,28 @@ def measure(args, world, rank, dev):
         ms_step = elapsed / args.steps * 1e3
         # dense algorithmic count for the ResNet workloads; for HRNet the executed FLOPs of the
         # conv/GEMM launches of one step (the engine's own 2*M*N*K accounting)
-        total_flops = sum(r["flops"] for r in recs) / max(n_instr, 1) if cfg.is_hrnet else forward_flops(cfg, B, size)
+        total_flops = (sum(r["flops"] for r in recs) / max(n_instr, 1) if (cfg.is_hrnet or cfg.learnable_query)
+                       else forward_flops(cfg, B, size))
         line = {
             "metric": "samples/sec (BxV frames) eval_fps.py, 8-view 256x256; 21-kpt L2 vs reference",
             "value": round(args.steps * B * V * world / elapsed, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" if args.input == "nchw" else "synthetic uint8 480x640 frames + crop windows (prepared on the device)",
-            "config": {"workload": f"{'BASELINE configs[2]' if args.workload == 'cfg3' else ('BASELINE configs[1]' if args.workload == 'cfg2' else 'HRNet release-config backbone')}: B={B}/GPU x V={V} x {size}x{size}, "
-                                   f"{'hrnet_' if cfg.is_hrnet else 'resnet'}{bt} backbone, d={cfg.feat_dim}, cross_attn x{cfg.fusion_layers}, GCN decoder",
+            "config": {"workload": f"{ {'cfg3': 'BASELINE configs[2]', 'cfg2': 'BASELINE configs[1]', 'cfg1': 'BASELINE configs[0] (HO3D_HandMvNet.yaml shape)'}.get(args.workload, 'HRNet release-config backbone') }: B={B}/GPU x V={V} x {size}x{size}, "
+                                   f"{'hrnet_' if cfg.is_hrnet else 'resnet'}{bt} backbone, d={cfg.feat_dim}, {args.fusion} x{cfg.fusion_layers}, GCN decoder",
                        "global_batch": B * world, "views": V, "frame": size, "parallelism": f"sample-shard x{world}"},
             "roofline": roofline,
+            "communicator": {"ranks_seen": ranks_seen, "backend": dist.get_backend() if world > 1 else None,
+                             "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["device"]) for r in ranks}),
+                             "collectives_per_step": (ranks[0]["collectives"] // max(args.warmup + args.steps + (args.steps if every == 0 else 0), 1)) if world > 1 else 0,
+                             "ranks": ranks},
+            "launches_per_forward": launches,
             "timed_region": {"instrumented_steps": n_instr if every > 0 else 0,
                              "note": "hipEvent pair around every conv/GEMM launch on the instrumented steps" if every > 0
                                      else "no events in the timed region; roofline from a separate instrumented pass of the same steps",
                              "hipgraph": {"enabled": bool(args.graphs), "cached": graph_stats[0], "replays": graph_stats[1]}},
-            "forward": {"algorithmic_gflop": round(total_flops / 1e9, 1),
-                        "tflops": round(total_flops / (ms_step * 1e-3) / 1e12, 2),
-                        "frac_of_f32_mfma_peak": round(total_flops / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "forward": forward_block(args.dtype, total_flops, ms_step, fam, n_instr),
             "kernels": {k: {"ms_per_step": round(v["ms"] / n_instr, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                             "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "bound": v["bound"], "frac": round(v["frac"], 4)}
                         for k, v in fam.items()},
@@ -317,6 +356,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override samples per GPU")
+    ap.add_argument("--fusion", default="cross_attn", choices=["cross_attn", "cross_attn_learnable_query"],
+                    help="model.fusion (every release config: cross_attn; the learnable-query module is SURVEY 8(f) row 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f32x3"],

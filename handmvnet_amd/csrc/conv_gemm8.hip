@@ -1,0 +1,280 @@
+// conv_gemm8.hip -- the fp16 256 x 256 GEMM tile on a counted-vmcnt, phase-interleaved main loop.
+//
+// Replaces, for the fp16 path's MFMA-heavy 1x1 convolutions (/root/reference/src/models/backbones/resnet.py:124-131 conv1 of
+// layer3's Bottlenecks, K = 1024; handmvnet.py:70-86 pose_net.0, K = 1024; the conv3 + downsample GEMM of a layer's first block,
+// K = planes + inplanes), conv_igemm's main loop: two tile buffers, ONE `vmcnt(0)` + ONE barrier per 64-wide k-step with all
+// eight waves reading their fragments, then all issuing MFMAs, in lock step.  That structure is tuned for the 64-cycle fp32
+// MFMA; with 32-cycle fp16 MFMAs it leaves the matrix pipe idle for every fragment-read burst and every drained DMA
+// (MFMA-busy 0.19 .. 0.53).  /opt/skills/guides/cdna_hip_programming.md section 5 gives the structure that does
+// better on gfx950 (its "256^2 8-phase template"); this is that structure for our operand roles and tile decomposition:
+//
+//   * a k-step is FOUR phases, each {fragment reads . DMA of one half-tile . [counted wait] . barrier . 8 MFMAs . barrier}:
+//         phase   MFMAs (pixel blocks a, channel block b)   fragment reads          DMA issued (tile t + 1)   wait
+//           1     a = 0,1  b = 0                            P[0,1] (8), W0 (4)      pixel half 0              vmcnt(4)
+//           2     a = 0,1  b = 1                            W1 (4)                  weight half 0             vmcnt(4)
+//           3     a = 2,3  b = 1                            P[2,3] (8)              weight half 1             --
+//           4     a = 2,3  b = 0                            --                      pixel half 1              vmcnt(4)
+//     a wave's 128 x 64 sub-tile = 4 x 2 accumulator blocks; every block gets the four k16 MFMAs of the step inside ONE phase,
+//     in ascending k: the same accumulation order as conv_igemm, hence the same bits.
+//   * the two wave halves (pixel rows 0-127 / 128-255) run ONE BARRIER APART: while one half issues its 8 MFMAs the other
+//     reads fragments and issues DMAs, so each SIMD's matrix pipe alternates between its two waves instead of idling.
+//   * `s_waitcnt vmcnt(4)`, never 0: a half-tile is two DMA instructions per thread, two half-tiles are always in flight across
+//     the barriers (raw s_barrier + lgkmcnt only).  A half-tile is read one phase after the wait that retires it (the wait
+//     precedes a barrier that every reader passes); a buffer is restaged a full k-step after its last read.
+//   * LDS: 2 k-steps x 4 half-tiles x [128 rows][64 halfs] = 128 KB, XOR-swizzled on the DMA source side like conv_igemm.
+//     Half-tiles are cut along the phase boundaries: pixel half h = blocks 2h, 2h + 1 of both wave rows; weight half h =
+//     block h of all four wave columns.
+// Operand roles, bias-as-initial-accumulator and the register epilogue are conv_igemm's transposed-output path.
+#include <cstdio>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace hmv {
+
+typedef float gf32x16 __attribute__((ext_vector_type(16)));
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 gf16x8 __attribute__((ext_vector_type(8)));
+
+#define HMV_GGLDS16(gptr, lptr)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+// DUAL: the reduction is the concatenation [first source | second source] (conv3 + downsample as one GEMM, ConvParams::in2)
+template <bool DUAL>
+__global__ __launch_bounds__(512, 2) void conv_gemm8_f16(const ConvParams p) {
+    constexpr int HT = 128 * 64;   // halfs per half-tile
+    extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];   // [2 k-steps][A0, A1, B0, B1][128][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // ---- XCD-aware tile assignment (bijective for any grid size), as conv_igemm
+    int mt, nt;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        mt = lid / p.ntiles;
+        nt = lid - mt * p.ntiles;
+    }
+    const _Float16 *zero = reinterpret_cast<const _Float16 *>(p.zero);
+    const int nk = p.Kpad >> 6;
+
+    // ---- DMA roles.  Thread -> row (tid >> 3) + 64 i of a half-tile, physical chunk tid & 7 holding logical chunk kqs.
+    const int kqs = (tid & 7) ^ ((tid >> 4) & 7);
+    // pixel half h, pass i: half-row hr = (tid >> 3) + 64 i -> wave row hr >> 6, block 2h + ((hr >> 5) & 1), line hr & 31
+    int aoff[2][2];          // element offset of the row in the first source (-1: past M, zero page)
+    int aoff2[2][2];         // ... in the second source
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hr = (tid >> 3) + 64 * i;
+            const int m = mt * 256 + (hr >> 6) * 128 + (2 * h + ((hr >> 5) & 1)) * 32 + (hr & 31);
+            aoff[h][i] = m < p.M ? m * p.lda + 8 * kqs : -1;
+            aoff2[h][i] = -1;
+            if constexpr (DUAL) {
+                if (m < p.M) {
+                    const int hw = p.Ho * p.Wo, n = m / hw, rem = m - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    aoff2[h][i] = ((n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.lda2 + 8 * kqs;
+                }
+            }
+        }
+    // weight half h, pass i: half-row hr -> wave column hr >> 5, block h, line hr & 31
+    const _Float16 *wsrc[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hr = (tid >> 3) + 64 * i;
+            wsrc[h][i] = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(nt * 256 + (hr >> 5) * 64 + h * 32 + (hr & 31)) * p.ldw + 8 * kqs;
+        }
+    const _Float16 *Ain = reinterpret_cast<const _Float16 *>(p.in), *Ain2 = reinterpret_cast<const _Float16 *>(p.in2);
+
+    // half-tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of k-step t (t >= nk: dummies from the zero page, nobody reads them)
+    auto stage = [&](int t, int which) {
+        _Float16 *dst = gsm + ((t & 1) * 4 + which) * HT + wave * 8 * 64;
+        const bool live = t < nk;
+        const int k0 = t << 6;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const _Float16 *src = zero;
+            if (which < 2) {
+                if constexpr (DUAL) {
+                    if (live && k0 >= p.ksplit) { if (aoff2[which][i] >= 0) src = Ain2 + (size_t)aoff2[which][i] + (k0 - p.ksplit); }
+                    else if (live && aoff[which][i] >= 0) src = Ain + (size_t)aoff[which][i] + k0;
+                } else {
+                    if (live && aoff[which][i] >= 0) src = Ain + (size_t)aoff[which][i] + k0;
+                }
+            } else if (live) {
+                src = wsrc[which - 2][i] + k0;
+            }
+            asm volatile("" : "+v"(src));   // ONE DMA instruction per schedule entry
+            HMV_GGLDS16(src, dst + i * 64 * 64);
+        }
+    };
+
+    // ---- accumulators start at the bias (transposed output: a register is ONE channel for all of the lane's pixels)
+    gf32x16 acc[4][2];
+    {
+        const float binit = 1.f / p.acc_scale;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float *bp = p.bias + nt * 256 + wn * 64 + 32 * b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const gf32x4 bq = *reinterpret_cast<const gf32x4 *>(bp + 16 * (q >> 1) + 8 * kh + 4 * (q & 1));
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[a][b][4 * q + u] = bq[u] * binit;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias loads: the counted waits below see DMAs only
+
+    // fragment addresses: pixel block a -> half a >> 1, half-row wm * 64 + (a & 1) * 32 + l31; weight block b -> half b,
+    // half-row wn * 32 + swap23(l31) (the row swap makes registers 8j .. 8j+7 eight consecutive channels)
+    const int wl31 = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int fsw = (l31 >> 1) & 7, fswb = (wl31 >> 1) & 7;
+    const int prow = (wm * 64 + l31) * 64, wrow = (wn * 32 + wl31) * 64;
+    gf16x8 fa[2][4], fb0[4], fb1[4];
+#define G8_READ_P(t, h)                                                                                     \
+    _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                    \
+            fa[a_][q_] = *reinterpret_cast<const gf16x8 *>(gsm + (((t) & 1) * 4 + (h)) * HT + prow + a_ * 32 * 64 + (((2 * q_ + kh) ^ fsw) * 8));
+#define G8_READ_W(t, h, FB)                                                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                        \
+        FB[q_] = *reinterpret_cast<const gf16x8 *>(gsm + (((t) & 1) * 4 + 2 + (h)) * HT + wrow + (((2 * q_ + kh) ^ fswb) * 8));
+#define G8_MFMA(A0, B, FB)                                                                                  \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                        \
+        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                                    \
+            acc[(A0) + a_][B] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FB[q_], fa[a_][q_], acc[(A0) + a_][B], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+// raw barrier, no vmcnt / lgkmcnt: the DMAs stay in flight across it; the compiler itself waits (lgkmcnt) for the fragments an
+// MFMA reads, and sched_barrier(0) keeps the MFMA cluster between its two barriers
+#define G8_BAR()                                                                                            \
+    asm volatile("s_barrier" ::: "memory");                                                                 \
+    __builtin_amdgcn_sched_barrier(0)
+#define G8_WAIT4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+
+    // ---- prologue: k-step 0 goes out whole in phase order; its first two half-tiles must have landed
+    stage(0, 0);
+    stage(0, 2);
+    stage(0, 3);
+    stage(0, 1);
+    G8_WAIT4();
+    G8_BAR();
+    if (wm == 1) G8_BAR();   // the second wave half runs one barrier behind the first from here on
+
+    for (int t = 0; t < nk; ++t) {
+        // phase 1
+        G8_READ_W(t, 0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        G8_READ_P(t, 0);
+        stage(t + 1, 0);
+        G8_WAIT4();            // weight half 1 of this k-step (read in phase 2) has landed
+        G8_BAR();
+        G8_MFMA(0, 0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        G8_BAR();
+        // phase 2
+        G8_READ_W(t, 1, fb1);
+        stage(t + 1, 2);
+        G8_WAIT4();            // pixel half 1 of this k-step (read in phase 3) has landed
+        G8_BAR();
+        G8_MFMA(0, 1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        G8_BAR();
+        // phase 3
+        G8_READ_P(t, 1);
+        stage(t + 1, 3);
+        G8_BAR();
+        G8_MFMA(2, 1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        G8_BAR();
+        // phase 4
+        stage(t + 1, 1);
+        G8_WAIT4();            // pixel half 0 and weight half 0 of k-step t + 1 (read in its phase 1) have landed
+        G8_BAR();
+        G8_MFMA(2, 0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        G8_BAR();
+    }
+    if (wm == 0) G8_BAR();   // the first half waits for the second: barrier counts match
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy DMAs of k-step nk must not outlive the LDS allocation
+#undef G8_READ_P
+#undef G8_READ_W
+#undef G8_MFMA
+#undef G8_BAR
+#undef G8_WAIT4
+
+    // ---- epilogue straight from the accumulators (conv_igemm's register path without a residual):
+    //   register 8j + u of block (a, b) = channel 32 b + 16 j + 8 kh + u of pixel row 32 a + l31
+    const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    const int nb0 = nt * 256 + wn * 64;
+    const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 7) & ~7);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int m = mt * 256 + wm * 128 + 32 * a + l31;
+        _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = nb0 + 32 * b + 16 * j + 8 * kh;
+                gf16x8 hv;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + 0.f, lo);
+                if (m < p.M && col < cend) *reinterpret_cast<gf16x8 *>(orow + col) = hv;
+            }
+    }
+}
+
+// ====================================================================== host side
+static int g_gemm8_mode = -1;   // -1: the launcher's rule (HMV_NO_GEMM8=1 disables it); 0 never; 1 whenever supported (op-level tests)
+void conv_gemm8_set_mode(int mode) { g_gemm8_mode = mode; }
+
+bool conv_gemm8_supported(const ConvParams &p) {
+    static int off = -1;   // development knob: HMV_NO_GEMM8=1 keeps these convs on conv_igemm (A/B runs)
+    if (off < 0) off = getenv("HMV_NO_GEMM8") ? 1 : 0;
+    if (g_gemm8_mode == 0 || (g_gemm8_mode < 0 && off)) return false;
+    if (!p.in_f16 || !p.out_f16 || p.res || p.R != 1 || p.S != 1 || p.pad_h || p.pad_w || p.up || p.ksl > 1 || p.phases > 1) return false;
+    if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out) return false;
+    if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
+    if (p.Kpad % 64 || p.Kpad < 128 || (p.ldc & 7) || ((p.lda ? p.lda : p.Cin) & 7) || ((p.ldw ? p.ldw : p.Kpad) & 7)) return false;
+    if (p.in2) {
+        if (p.ksplit % 64 || p.ksplit <= 0 || p.ksplit >= p.Kpad || (p.lda2 & 7) || p.stride != 1) return false;
+        if ((long long)p.N * p.H2 * p.W2 * p.lda2 >= (1ll << 31)) return false;
+    } else if (p.stride != 1) {
+        return false;
+    }
+    if ((long long)p.M * (p.lda ? p.lda : p.Cin) >= (1ll << 31)) return false;   // 32-bit element offsets of the pixel rows
+    if (g_gemm8_mode > 0) return true;
+    // the launcher's rule: the shapes conv_pick_tile gives the 256 x 256 tile (Cout > 128, >= 512 tiles)
+    return p.Cout > 128 && (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256) >= 512;
+}
+
+hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name) {
+    constexpr size_t lds = (size_t)2 * 4 * 128 * 64 * sizeof(_Float16);
+    static bool configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!configured[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8_f16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8_f16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[dev] = true;
+    }
+    p.mtiles = (p.M + 255) / 256;
+    p.ntiles = (p.Cout + 255) / 256;
+    if (name) *name = p.in2 ? "conv_gemm8_f16<256x256,1x1,dual>" : "conv_gemm8_f16<256x256,1x1>";
+    if (p.in2) hipLaunchKernelGGL(conv_gemm8_f16<true>, dim3(p.mtiles * p.ntiles), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL(conv_gemm8_f16<false>, dim3(p.mtiles * p.ntiles), dim3(512), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace hmv

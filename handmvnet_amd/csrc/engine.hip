@@ -204,6 +204,9 @@ struct hmv_engine {
     typedef std::array<uintptr_t, 12> GraphKey;
     struct GraphEntry { GraphKey key; hipGraphExec_t exec; unsigned long long stamp; };
     bool graphs = false;
+    // fused tail kernels (fusion_kernels.hip); HMV_NO_FFFUSE=1 / HMV_NO_CHEBFUSE=1 in the environment or hmv_set_tail_fusion(h, 0)
+    // select the launch-per-op path (A/B runs, the equivalence test).  Part of the workspace plan: changing them re-plans.
+    bool ff_fuse = true, cheb_fuse = true;
     std::vector<GraphEntry> gcache;
     std::vector<GraphKey> gseen;     // buffer sets run eagerly once and not captured yet (callers often alternate between a few)
     hipStream_t gstream = nullptr;   // capture happens here (the caller's stream may be the NULL stream, which cannot capture)
@@ -217,6 +220,7 @@ struct hmv_engine {
     bool profiling = false;
     std::vector<ProfRec> prof;
     size_t prof_used = 0;
+    int launches = 0;      // device operations (kernels, memsets, copies) enqueued by the last eager / captured forward
 
     int fail(int code, const char *fmt, ...) {
         char buf[512];
@@ -509,6 +513,8 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     if (cfg->device < 0 || cfg->device >= ndev) return bad("device ordinal out of range");
     hmv_engine *h = new hmv_engine();
     if (const char *g = getenv("HMV_GRAPHS")) h->graphs = atoi(g) != 0;
+    h->ff_fuse = getenv("HMV_NO_FFFUSE") == nullptr;
+    h->cheb_fuse = getenv("HMV_NO_CHEBFUSE") == nullptr;
     h->cfg = *cfg;
     h->paper = paper;
     h->hrnet = hrnet;
@@ -1022,7 +1028,12 @@ struct Runner {
     int rc = HMV_OK;
     Arena &A;
 
-    float *alloc(size_t n) { return A.alloc(n); }
+    float *alloc(size_t n) {
+        float *ptr = A.alloc(n);
+        // a real run must stay inside the reservation its planning run sized: stop launching before anything touches memory past it
+        if (!dry && h->arena_bytes && A.high > h->arena_bytes && rc == HMV_OK) rc = h->fail(HMV_ERR_STATE, "workspace plan exceeded its reservation");
+        return ptr;
+    }
     void release(float *p) { A.release(p); }
 
     void check(hipError_t e, const char *what) {
@@ -1112,6 +1123,7 @@ struct Runner {
         }
         const char *kname = nullptr;
         check(launch_conv(p, tile, s, &kname), L.label.c_str());
+        ++h->launches;
         if (kernel_name) *kernel_name = kname;
         if (pr) {
             pr->name = kname;
@@ -1145,11 +1157,44 @@ struct Runner {
         conv(Ls, a, rows, 1, 1, 1, 0, 0, slab, lds_, nullptr, 0, ACT_NONE, 1, 1);
         ksplit = 1;
         if (!dry && rc == HMV_OK) {
+            ++h->launches;
             if (ln.y)   // the consumer is a LayerNorm (gemm_ln below): slice sum, bias and residual become its load
                 check(launch_splitk_layernorm(slab, S, rows, lds_, L.Cout, L.bias, res, ldr, rg_out, rg_in, ln.g1, ln.b1, ln.y, ln.ldy,
                                               ln.g2, ln.b2, ln.y2, s), "splitk_layernorm");
             else
                 check(launch_splitk_reduce(slab, S, rows, lds_, L.Cout, L.bias, res, ldr, rg_out, rg_in, act, out, ldc, s), "splitk_reduce");
+        }
+        release(slab);
+    }
+
+    // Everything of a fusion block behind the attention in two launches: the split-K to_out GEMM, then ONE kernel for
+    // (slice sum + bias + residual) -> [LayerNorm1] -> FeedForward (LayerNorm, Linear, GELU, Linear, + residual) -> [LayerNorm2]
+    // (fusion_kernels.hip).  Same alloc / release sequence in the dry (planning) run.
+    bool ff_fusable(const Layer &out, const Layer &ff1, const Layer &ff2, int rows, int ldt) const {
+        return h->ff_fuse && splitk_slices(out, rows) > 1 && !ff1.f16 && !ff2.f16 && !ff1.plane && !ff2.plane &&
+               ff1.Kpad == ldt && ldt % 16 == 0 && (ff1.Cout == 128 || ff1.Cout == 256) && ff2.Kpad == ff1.Cout && ff2.Cout_pad >= ldt &&
+               ldt <= 1024;
+    }
+    void ff_block(const Layer &out, const Layer &ff1, const Layer &ff2, const float *att, int rows, const float *res, int ldr, int rg_out,
+                  int rg_in, const float *n1g, const float *n1b, const float *fg, const float *fb, const float *n2g, const float *n2b,
+                  float *y, int ldt, int d) {
+        const int S = splitk_slices(out, rows), lds_ = (out.Cout + 3) / 4 * 4;
+        float *slab = alloc((size_t)S * rows * lds_);
+        Layer Ls = out;
+        Ls.bias = h->zero_bias;
+        ksplit = S;
+        conv(Ls, att, rows, 1, 1, 1, 0, 0, slab, lds_, nullptr, 0, ACT_NONE, 1, 1);
+        ksplit = 1;
+        if (!dry && rc == HMV_OK) {
+            FfBlockParams p{};
+            p.slab = slab; p.S = S; p.slice = (size_t)rows * lds_; p.lds = lds_; p.bias0 = out.bias;
+            p.res = res; p.ldr = ldr; p.rg_out = rg_out; p.rg_in = rg_in;
+            p.rows = rows; p.d = d; p.ld = ldt;
+            p.n1g = n1g; p.n1b = n1b; p.fg = fg; p.fb = fb; p.n2g = n2g; p.n2b = n2b;
+            p.w1 = ff1.w; p.b1 = ff1.bias; p.ldw1 = ff1.Kpad; p.w2 = ff2.w; p.b2 = ff2.bias; p.ldw2 = ff2.Kpad;
+            p.out = y; p.ldo = ldt; p.hid = ff1.Cout;
+            check(launch_ff_block(p, s), "ff_block");
+            ++h->launches;
         }
         release(slab);
     }
@@ -1167,7 +1212,7 @@ struct Runner {
         }
         float *o = alloc((size_t)rows * ldy);
         gemm(L, a, rows, o, ldy, res, ldr, ACT_NONE, rg_out, rg_in);
-        if (!dry && rc == HMV_OK) check(launch_layernorm(o, ldy, rows, L.Cout, g1, b1, y, ldy, g2, b2, y2, s), "layernorm");
+        if (!dry && rc == HMV_OK) { check(launch_layernorm(o, ldy, rows, L.Cout, g1, b1, y, ldy, g2, b2, y2, s), "layernorm"); ++h->launches; }
         release(o);
     }
 };
@@ -1183,7 +1228,7 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     const bool h16 = c.dtype != HMV_F32;      // the conv stack runs on the fp16 kernels ...
     const bool split = c.dtype == HMV_F32X3;  // ... on (hi, lo) pairs: 4 bytes per element like fp32
 #define ACT(n) ((h16 && !split) ? ((size_t)(n) + 1) / 2 : (size_t)(n))
-#define LAUNCH(expr) do { if (!dry && R.rc == HMV_OK) R.check((expr), #expr); } while (0)
+#define LAUNCH(expr) do { if (!dry && R.rc == HMV_OK) { R.check((expr), #expr); ++h->launches; } } while (0)
 
     // sampled feature levels in the reference's feats[] order (handmvnet.py:165-177), channels-last with row stride ld
     float *lvl[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1505,20 +1550,32 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
             LAUNCH(launch_add_pe(X, ldt, rows, Tcur, d, h->pe, xp, ldt, s));
             R.release(X);
             float *att = R.alloc((size_t)qrows * INNER_LQ);
-            float *o = R.alloc((size_t)qrows * ldt);
             if (cross) {
                 float *kv = R.alloc((size_t)rows * 2 * INNER_LQ);
                 project(a.kv, xp, rows, kv, 2 * INNER_LQ);
                 LAUNCH(launch_attention_d256(a.qprobe, INNER_LQ, 0, kv, kv + INNER_LQ, 2 * INNER_LQ, B, Tcur, Tq, att, s));
                 R.release(kv);
-                R.gemm(a.out, att, qrows, o, ldt, nullptr, 0, ACT_NONE);   // out = to_out(att); no residual from the tokens
             } else {
                 float *qkv = R.alloc((size_t)rows * 3 * INNER_LQ);
                 project(a.qkv, xp, rows, qkv, 3 * INNER_LQ);
                 LAUNCH(launch_attention_d256(qkv, 3 * INNER_LQ, Tcur, qkv + INNER_LQ, qkv + 2 * INNER_LQ, 3 * INNER_LQ, B, Tcur, Tq, att, s));
                 R.release(qkv);
-                R.gemm(a.out, att, qrows, o, ldt, xp, ldt, ACT_NONE);      // out = to_out(att) + x
             }
+            if (R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt)) {
+                // out = to_out(att) (+ x, not in the probe block); out = ff(out) + out: no LayerNorm around the attention, the
+                // FeedForward keeps its own; pad columns come out as zeros
+                float *Xf = R.alloc((size_t)qrows * ldt);
+                R.ff_block(a.out, a.ff1, a.ff2, att, qrows, cross ? nullptr : xp, ldt, 0, 0, nullptr, nullptr, a.fg, a.fb, nullptr, nullptr,
+                           Xf, ldt, d);
+                R.release(att);
+                R.release(xp);
+                X = Xf;
+                Tcur = Tq;
+                continue;
+            }
+            float *o = R.alloc((size_t)qrows * ldt);
+            if (cross) R.gemm(a.out, att, qrows, o, ldt, nullptr, 0, ACT_NONE);   // out = to_out(att); no residual from the tokens
+            else R.gemm(a.out, att, qrows, o, ldt, xp, ldt, ACT_NONE);            // out = to_out(att) + x
             R.release(att);
             R.release(xp);
             float *f0 = R.alloc((size_t)qrows * ldt);
@@ -1551,6 +1608,16 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         if (Tk > 0) LAUNCH(launch_attention(qkv, B, Tcur, Tq, koff, Tk, att, s));
         else LAUNCH(hipMemsetAsync(att, 0, (size_t)qrows * INNER * sizeof(float), s));
         R.release(qkv);
+        if (R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt)) {   // norm1(to_out + _q) -> FeedForward -> norm2 in one launch behind the GEMM
+            float *Xf = R.alloc((size_t)qrows * ldt);
+            R.ff_block(a.out, a.ff1, a.ff2, att, qrows, X, ldt, cross ? Tq : 0, cross ? Tcur : 0, a.n1g, a.n1b, a.fg, a.fb, a.n2g, a.n2b, Xf,
+                       ldt, d);
+            R.release(att);
+            R.release(X);
+            X = Xf;
+            Tcur = Tq;
+            continue;
+        }
         float *n1 = R.alloc((size_t)qrows * ldt), *f0 = R.alloc((size_t)qrows * ldt);
         R.gemm_ln(a.out, att, qrows, X, ldt, cross ? Tq : 0, cross ? Tcur : 0, a.n1g, a.n1b, n1, ldt, a.fg, a.fb, f0);  // norm1(to_out + _q), ff LN
         R.release(att);
@@ -1572,7 +1639,22 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
 
     // ---- decoder (nets.py:133-139 / 150-154)
     const int jr = B * NJ;
-    if (c.decoder == HMV_DECODER_GCN) {
+    if (c.decoder == HMV_DECODER_GCN && h->cheb_fuse && ldt % 16 == 0 && h->gcn[0].Kpad == ldt) {
+        // the three ChebConv layers in two launches (fusion_kernels.hip): layer 1 per (sample, 16 channels), layers 2 + 3 per sample
+        float *scr = R.alloc((size_t)jr * 256);
+        if (!dry && R.rc == HMV_OK) {
+            ChebFusedParams p{};
+            p.x = X; p.ldx = ldt; p.B = B; p.K = ldt;
+            p.w1 = h->gcn[0].w; p.ldw1 = h->gcn[0].Kpad; p.c1 = 256; p.bias1 = h->gcn_bias[0];
+            p.w2 = h->gcn[1].w; p.ldw2 = h->gcn[1].Kpad; p.c2 = 64; p.bias2 = h->gcn_bias[1];
+            p.w3 = h->gcn[2].w; p.ldw3 = h->gcn[2].Kpad; p.c3 = 3; p.bias3 = h->gcn_bias[2];
+            p.tk = h->cheb_t; p.scratch = scr; p.out = joints_cam; p.ldo = 3;
+            R.check(launch_cheb_fused(p, s), "cheb_fused");
+            h->launches += 2;
+        }
+        R.release(X);
+        R.release(scr);
+    } else if (c.decoder == HMV_DECODER_GCN) {
         const int dims[4] = {d, 256, 64, 3};
         float *xin = X;
         for (int i = 0; i < 3; ++i) {
@@ -1658,6 +1740,7 @@ int hmv_reserve(hmv_handle h, int32_t batch) {
 static int forward_eager(hmv_handle h, int32_t batch, const float *x, const float *bbox, const float *intrinsic,
                          float *joints_crop_img, float *joints_cam, float *heatmap, hipStream_t stream) {
     h->plan.reset(h->arena);
+    h->launches = 0;
     const int rc = run_forward(h, batch, x, bbox, intrinsic, joints_crop_img, joints_cam, heatmap, stream, false, h->plan);
     if (rc == HMV_OK && h->plan.high > h->arena_bytes) return h->fail(HMV_ERR_STATE, "workspace plan exceeded its reservation");
     return rc;
@@ -1808,6 +1891,18 @@ int hmv_poison_workspace(hmv_handle h, int32_t value, void *stream) {
     return HMV_OK;
 }
 
+/* Fused tail kernels on (default) / off (the launch-per-op path they replace).  The choice is part of the workspace plan, so the
+ * workspace is re-planned on the next forward. */
+int hmv_set_tail_fusion(hmv_handle h, int32_t enable) {
+    if (!h) return HMV_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    h->drop_graphs();
+    h->ff_fuse = h->cheb_fuse = enable != 0;
+    h->reserved_batch = 0;   // forces hmv_reserve to size the workspace again
+    return HMV_OK;
+}
+
 int hmv_set_capture(hmv_handle h, int32_t enable) {
     if (!h) return HMV_ERR_ARG;
     h->capture = enable != 0;
@@ -1839,6 +1934,9 @@ int hmv_set_profiling(hmv_handle h, int32_t enable) {
 
 int hmv_profile_count(hmv_handle h) { return h ? (int)h->prof_used : 0; }
 
+/* Device operations (kernel launches, memsets, device copies) the last eagerly run forward enqueued. */
+int hmv_launch_count(hmv_handle h) { return h ? h->launches : 0; }
+
 int hmv_profile_get(hmv_handle h, int32_t index, const char **name, const char **label, float *ms, double *flops) {
     if (!h || index < 0 || (size_t)index >= h->prof_used) return HMV_ERR_ARG;
     ProfRec &r = h->prof[index];
@@ -1865,6 +1963,18 @@ int hmv_op_attention(int32_t device, const float *qkv, int32_t B, int32_t T, int
     }
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
     const hipError_t e = launch_attention(qkv, B, T, Tq, koff, Tk, out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) { g_create_err = std::string("attention launch failed: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
+    return HMV_OK;
+}
+
+int hmv_op_attention_lq(int32_t device, const float *q, int32_t q_ld, int32_t q_bstride, const float *k, const float *v, int32_t kv_ld,
+                        int32_t B, int32_t T, int32_t Tq, float *out, void *stream) {
+    if (!q || !k || !v || !out || B <= 0 || T <= 0 || Tq <= 0 || q_ld < 2048 || kv_ld < 2048 || q_bstride < 0 || (q_ld & 3) || (kv_ld & 3)) {
+        g_create_err = "hmv_op_attention_lq: bad argument";
+        return HMV_ERR_ARG;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
+    const hipError_t e = launch_attention_d256(q, q_ld, q_bstride, k, v, kv_ld, B, T, Tq, out, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) { g_create_err = std::string("attention launch failed: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
     return HMV_OK;
 }
@@ -1983,8 +2093,10 @@ extern "C" int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int
                                  void *stream) {
     if (kernel_sel < 0 || kernel_sel > 2) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0, 1 or 2"; return HMV_ERR_ARG; }
     conv_stream_set_mode(kernel_sel == 0 ? -1 : kernel_sel - 1);
+    conv_gemm8_set_mode(kernel_sel == 0 ? -1 : kernel_sel - 1);
     const int rc = op_conv2d_any("hmv_op_conv2d_f16", device, HMV_F16, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad,
                                  residual, relu, out_f16, true, kernel_name, stream);
     conv_stream_set_mode(-1);
+    conv_gemm8_set_mode(-1);
     return rc;
 }

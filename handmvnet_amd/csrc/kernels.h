@@ -143,6 +143,41 @@ hipError_t launch_splitk_reduce(const float *slab, int S, int rows, int lds, int
 // Chebyshev mix: out[b][i][o] = act(sum_k sum_j Tk[k][i][j] * y[b*21+j][k*co + o] + bias[o])
 hipError_t launch_cheb_mix(const float *y, int ldy, int B, int co, const float *tk, const float *bias, int leaky,
                            float *out, int ldo, hipStream_t s);
+// conv_gemm8.hip: the fp16 256 x 256 1x1 tile (no residual; optional second source) on the counted-vmcnt, phase-interleaved
+// main loop; launch_conv routes to it when conv_gemm8_supported(p).  Bit-identical to conv_igemm's result.
+bool conv_gemm8_supported(const ConvParams &p);
+void conv_gemm8_set_mode(int mode);   // -1 launcher's rule, 0 never, 1 whenever supported (op-level tests)
+hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name);
+
+// ---- fusion_kernels.hip: the launch-bound tail as fused kernels
+// Everything of a fusion block behind its to_out GEMM (layers.py:224-233 / 161-174; learnable-query blocks: layers.py:293-299):
+//   t = (slab: sum of S split-K slices + bias0 + residual row | x row);  n1 = n1g ? LN(t) : t;  f0 = LN_ff(n1);
+//   h = GELU(f0 W1^T + b1);  f2 = h W2^T + b2 + n1;  out = n2g ? LN(f2) : f2   (pad columns [d, ldo) written as zeros)
+struct FfBlockParams {
+    const float *slab; int S; size_t slice; int lds; const float *bias0; const float *res; int ldr, rg_out, rg_in;
+    const float *x; int ldx;
+    int rows, d, ld;                       // token rows, feature width, padded width (= K of W1, multiple of 16)
+    const float *n1g, *n1b, *fg, *fb;
+    const float *w1, *b1; int ldw1;        // [hid (+pad)][ldw1 >= ld]
+    const float *w2, *b2; int ldw2;        // [>= ld rows][ldw2 >= hid]
+    const float *n2g, *n2b;
+    float *out; int ldo;
+    int hid;                               // 128 | 256
+};
+hipError_t launch_ff_block(const FfBlockParams &p, hipStream_t s);
+// JointsDecoderGCN (nets.py:133-139): three ChebConv layers K -> c1 -> c2 -> c3 in two launches (layer 1 per (sample, 16
+// channels); layers 2 + 3 per sample).  w_i: the packed [3 * c_i (+pad)][ld] matrices of the unfused GEMMs (row k * c_i + o).
+struct ChebFusedParams {
+    const float *x; int ldx; int B, K;
+    const float *w1; int ldw1; int c1; const float *bias1;
+    const float *w2; int ldw2; int c2; const float *bias2;
+    const float *w3; int ldw3; int c3; const float *bias3;
+    const float *tk;                       // [3][21][21]
+    float *scratch;                        // [B*21][c1]
+    float *out; int ldo;
+};
+hipError_t launch_cheb_fused(const ChebFusedParams &p, hipStream_t s);
+
 // NHWC -> NCHW copy (stage capture)
 hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t s, int ld = 0);
 hipError_t launch_copy_rows(const float *in, int ldi, float *out, int ldo, int rows, int cols, hipStream_t s);

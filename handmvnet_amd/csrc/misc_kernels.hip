@@ -586,60 +586,69 @@ hipError_t launch_splitk_layernorm(const float *slab, int S, int rows, int lds, 
 //                           the accumulator layout S^T came out in, so P never leaves the registers
 // The k order inside every 8-wide group is permuted identically for both operands (16-byte reads).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int ATT_LDK = 132;   // Q block row stride (floats): conflict-free ds_read_b128 of the B operand
 constexpr int ATT_WAVES = 4;
-constexpr int ATT_Q_FLOATS = 32 * ATT_LDK;
-constexpr int ATT_V_FLOATS = 8 * 128;                        // per wave: a quarter of a chunk
-constexpr int ATT_LOOP_FLOATS = ATT_Q_FLOATS + ATT_WAVES * ATT_V_FLOATS;
-constexpr int ATT_MERGE_FLOATS = ATT_WAVES * 64 * 64 + 2 * ATT_WAVES * 32;   // O partials [w][c][e][lane], then max and sum [w][query]
-constexpr int ATT_LDS_FLOATS = ATT_LOOP_FLOATS > ATT_MERGE_FLOATS ? ATT_LOOP_FLOATS : ATT_MERGE_FLOATS;
+// D = head width: 128 (MultiHeadAttention, layers.py:177-237) or 256 (MultiHeadAttentionLearnableQuery, layers.py:240-301)
+template <int D> struct AttShape {
+    static constexpr int LDK = D + 4;                           // Q block row stride (floats): conflict-free ds_read_b128 of the B operand
+    static constexpr int NC = D / 32;                           // 32-channel blocks of the head
+    static constexpr int Q_FLOATS = 32 * LDK;
+    static constexpr int V_FLOATS = 8 * D;                      // per wave: a quarter of a chunk
+    static constexpr int LOOP_FLOATS = Q_FLOATS + ATT_WAVES * V_FLOATS;
+    static constexpr int MERGE_FLOATS = ATT_WAVES * NC * 16 * 64 + 2 * ATT_WAVES * 32;   // O partials [w][c][e][lane], then max and sum [w][query]
+    static constexpr int LDS_FLOATS = LOOP_FLOATS > MERGE_FLOATS ? LOOP_FLOATS : MERGE_FLOATS;
+};
 
 #ifndef HMV_ATT_OCC
-#define HMV_ATT_OCC 2   // workgroups per CU the register budget is set for
+#define HMV_ATT_OCC 2   // workgroups per CU the register budget is set for (128-wide heads; the 256-wide ones take the CU alone)
 #endif
-__global__ __launch_bounds__(64 * ATT_WAVES, HMV_ATT_OCC) void attention_mfma_kernel(const float *__restrict__ qkv, int T, int Tq, int koff, int Tk,
-                                                                           int nqb, float *__restrict__ out) {
+// q rows: q + (b * q_bstride + i) * q_ld + h * D;  k / v rows: k + (b * T + j) * kv_ld + h * D for keys j < Tk (the caller offsets
+// k / v to the first key);  out rows [B * Tq][8 * D]
+template <int D>
+__global__ __launch_bounds__(64 * ATT_WAVES, D == 128 ? HMV_ATT_OCC : 1) void attention_mfma_kernel(const float *__restrict__ q, int q_ld, int q_bstride,
+        const float *__restrict__ k, const float *__restrict__ v, int kv_ld, int T, int Tq, int Tk, int nqb, float *__restrict__ out) {
+    using SH = AttShape<D>;
+    constexpr int NC = SH::NC, NU = D / 8, NV = D / 32;   // K vectors per lane, V vectors per lane and quarter chunk
     extern __shared__ __attribute__((aligned(16))) float att_smem[];
     const int qblk = blockIdx.x % nqb, bh = blockIdx.x / nqb;
     const int b = bh >> 3, h = bh & 7;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const size_t ld = 3 * 1024;
-    const float *base = qkv + (size_t)b * T * ld;
-    const float *qb = base + h * 128, *kb = base + (size_t)koff * ld + 1024 + h * 128, *vb = base + (size_t)koff * ld + 2048 + h * 128;
+    const size_t ld = (size_t)kv_ld;
+    const float *qb = q + (size_t)b * q_bstride * q_ld + h * D;
+    const float *kb = k + (size_t)b * T * ld + h * D, *vb = v + (size_t)b * T * ld + h * D;
     const int nkc = (Tk + 31) >> 5;
-    const float scale = 0.08838834764831845f;  // 128 ** -0.5
-    float *sQ = att_smem;                                                   // [32][ATT_LDK]
-    float *sVw = att_smem + ATT_Q_FLOATS + wave * ATT_V_FLOATS;             // [8][128], this wave's
+    const float scale = D == 128 ? 0.08838834764831845f : 0.0625f;  // D ** -0.5
+    float *sQ = att_smem;                                                   // [32][LDK]
+    float *sVw = att_smem + SH::Q_FLOATS + wave * SH::V_FLOATS;             // [8][D], this wave's
 
     // every global load of a wave's first chunk is issued before anything waits
-    f32x4 kf[16], va[4], vb_[4];
+    f32x4 kf[NU], va[NV], vb_[NV];
     int kc = wave;
 #define ATT_LOAD_K(KC)                                                                                  \
     do {                                                                                                \
         const int key_ = (KC) * 32 + l31;                                                               \
         const bool kv_ = key_ < Tk;                                                                     \
         const float *krow_ = kb + (size_t)(kv_ ? key_ : 0) * ld + 4 * kh;                               \
-        _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                                \
+        _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                \
             kf[u] = *reinterpret_cast<const f32x4 *>(krow_ + 8 * u);                                    \
             if (!kv_) kf[u] = f32x4{0.f, 0.f, 0.f, 0.f};                                                \
         }                                                                                               \
     } while (0)
-    // 8 keys x 128 channels: 4 coalesced 16-byte vectors per lane (keys >= Tk are zeros)
+    // 8 keys x D channels: NV coalesced 16-byte vectors per lane (keys >= Tk are zeros)
 #define ATT_LOAD_V(KEY0, VR)                                                                            \
     do {                                                                                                \
-        _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                              \
-            const int idx_ = it * 64 + lane, k2_ = (KEY0) + (idx_ >> 5);                                \
+        _Pragma("unroll") for (int it = 0; it < NV; ++it) {                                             \
+            const int idx_ = it * 64 + lane, k2_ = (KEY0) + idx_ / (D / 4);                             \
             VR[it] = f32x4{0.f, 0.f, 0.f, 0.f};                                                         \
-            if (k2_ < Tk) VR[it] = *reinterpret_cast<const f32x4 *>(vb + (size_t)k2_ * ld + 4 * (idx_ & 31)); \
+            if (k2_ < Tk) VR[it] = *reinterpret_cast<const f32x4 *>(vb + (size_t)k2_ * ld + 4 * (idx_ % (D / 4))); \
         }                                                                                               \
     } while (0)
 #define ATT_STORE_V(VR)                                                                                 \
     do {                                                                                                \
         __builtin_amdgcn_wave_barrier();                                                                \
-        _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                              \
+        _Pragma("unroll") for (int it = 0; it < NV; ++it) {                                             \
             const int idx_ = it * 64 + lane;                                                            \
-            *reinterpret_cast<f32x4 *>(&sVw[(idx_ >> 5) * 128 + 4 * (idx_ & 31)]) = VR[it];             \
+            *reinterpret_cast<f32x4 *>(&sVw[(idx_ / (D / 4)) * D + 4 * (idx_ % (D / 4))]) = VR[it];     \
         }                                                                                               \
         __builtin_amdgcn_wave_barrier();                                                                \
     } while (0)
@@ -647,8 +656,8 @@ __global__ __launch_bounds__(64 * ATT_WAVES, HMV_ATT_OCC) void attention_mfma_ke
 #define ATT_PV(G)                                                                                       \
     do {                                                                                                \
         _Pragma("unroll") for (int e2 = 0; e2 < 4; ++e2) {                                              \
-            const float *vrow = &sVw[(4 * kh + e2) * 128 + l31];                                        \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c)                                               \
+            const float *vrow = &sVw[(4 * kh + e2) * D + l31];                                          \
+            _Pragma("unroll") for (int c = 0; c < NC; ++c)                                              \
                 o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * c], sacc[4 * (G) + e2], o[c], 0, 0, 0); \
         }                                                                                               \
     } while (0)
@@ -658,18 +667,18 @@ __global__ __launch_bounds__(64 * ATT_WAVES, HMV_ATT_OCC) void attention_mfma_ke
     }
     // Q block (rows >= Tq are zeros), shared by the 4 waves
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = it * 256 + tid, r = idx >> 5, c4 = idx & 31, row = qblk * 32 + r;
-        f32x4 q = {0.f, 0.f, 0.f, 0.f};
-        if (row < Tq) q = *reinterpret_cast<const f32x4 *>(qb + (size_t)row * ld + 4 * c4);
-        *reinterpret_cast<f32x4 *>(&sQ[r * ATT_LDK + 4 * c4]) = q;
+    for (int it = 0; it < D / 32; ++it) {
+        const int idx = it * 256 + tid, r = idx / (D / 4), c4 = idx % (D / 4), row = qblk * 32 + r;
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+        if (row < Tq) qv = *reinterpret_cast<const f32x4 *>(qb + (size_t)row * q_ld + 4 * c4);
+        *reinterpret_cast<f32x4 *>(&sQ[r * SH::LDK + 4 * c4]) = qv;
     }
     __syncthreads();
 
-    f32x16 o[4];   // o[c][e] on lane (q, half): O[q][32c + (e&3) + 8(e>>2) + 4 half]
+    f32x16 o[NC];   // o[c][e] on lane (q, half): O[q][32c + (e&3) + 8(e>>2) + 4 half]
     float m_run = -INFINITY, l_run = 0.f;   // of query l31, over the keys this lane has seen (its half of every chunk)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[c][e] = 0.f;
 
@@ -677,8 +686,8 @@ __global__ __launch_bounds__(64 * ATT_WAVES, HMV_ATT_OCC) void attention_mfma_ke
     do {                                                                                                \
         f32x16 sacc;                                                                                    \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) sacc[e] = 0.f;                                   \
-        _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                                \
-            const f32x4 qf = *reinterpret_cast<const f32x4 *>(&sQ[l31 * ATT_LDK + 8 * u + 4 * kh]);     \
+        _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                \
+            const f32x4 qf = *reinterpret_cast<const f32x4 *>(&sQ[l31 * SH::LDK + 8 * u + 4 * kh]);     \
             _Pragma("unroll") for (int e = 0; e < 4; ++e)                                               \
                 sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[e], sacc, 0, 0, 0);            \
         }                                                                                               \
@@ -700,7 +709,7 @@ __global__ __launch_bounds__(64 * ATT_WAVES, HMV_ATT_OCC) void attention_mfma_ke
         }                                                                                               \
         l_run = l_run * alpha + psum;                                                                   \
         m_run = m_new;                                                                                  \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                   \
+        _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                  \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) o[c][e] *= alpha;                            \
         /* 8 keys at a time through the wave's LDS buffer; the loads run two quarters ahead */          \
         ATT_STORE_V(va);                                                                                \
@@ -731,16 +740,15 @@ __global__ __launch_bounds__(64 * ATT_WAVES, HMV_ATT_OCC) void attention_mfma_ke
 
     // ---- merge the 4 waves' partials in wave order: out = sum_w O_w e^(m_w - M) / sum_w l_w e^(m_w - M)
     __syncthreads();   // the merge area aliases the loop's buffers
-    float *sO = att_smem, *sM = att_smem + ATT_WAVES * 64 * 64, *sL = sM + ATT_WAVES * 32;
+    float *sO = att_smem, *sM = att_smem + ATT_WAVES * NC * 16 * 64, *sL = sM + ATT_WAVES * 32;
     l_run += __shfl_xor(l_run, 32, 64);
     if (kh == 0) { sM[wave * 32 + l31] = m_run; sL[wave * 32 + l31] = l_run; }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sO[((wave * 4 + c) * 16 + e) * 64 + lane] = o[c][e];
+        for (int e = 0; e < 16; ++e) sO[((wave * NC + c) * 16 + e) * 64 + lane] = o[c][e];
     __syncthreads();
     {
-        const int c = wave;   // this wave finishes channel block c
         float M = sM[l31];
 #pragma unroll
         for (int w = 1; w < ATT_WAVES; ++w) M = fmaxf(M, sM[w * 32 + l31]);
@@ -753,33 +761,42 @@ __global__ __launch_bounds__(64 * ATT_WAVES, HMV_ATT_OCC) void attention_mfma_ke
         const float inv = 1.f / den;
         const int row = qblk * 32 + l31;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 r4;
+        for (int c = wave; c < NC; c += ATT_WAVES) {   // this wave finishes channel blocks wave, wave + 4, ..
 #pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) {
-                float num = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                f32x4 r4;
 #pragma unroll
-                for (int w = 0; w < ATT_WAVES; ++w) num += sO[((w * 4 + c) * 16 + 4 * g + e2) * 64 + lane] * a[w];
-                r4[e2] = num * inv;
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    float num = 0.f;
+#pragma unroll
+                    for (int w = 0; w < ATT_WAVES; ++w) num += sO[((w * NC + c) * 16 + 4 * g + e2) * 64 + lane] * a[w];
+                    r4[e2] = num * inv;
+                }
+                if (row < Tq) *reinterpret_cast<f32x4 *>(out + ((size_t)b * Tq + row) * (8 * D) + h * D + 32 * c + 8 * g + 4 * kh) = r4;
             }
-            if (row < Tq) *reinterpret_cast<f32x4 *>(out + ((size_t)b * Tq + row) * 1024 + h * 128 + 32 * c + 8 * g + 4 * kh) = r4;
         }
     }
 }
-hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s) {
+template <int D>
+static hipError_t launch_attention_any(const float *q, int q_ld, int q_bstride, const float *k, const float *v, int kv_ld, int B, int T, int Tq,
+                                       int Tk, float *out, hipStream_t s) {
     if (Tk <= 0 || Tq <= 0 || B <= 0) return hipErrorInvalidValue;
     static bool configured[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    const int lds = ATT_LDS_FLOATS * (int)sizeof(float);
+    const int lds = AttShape<D>::LDS_FLOATS * (int)sizeof(float);
     if (!configured[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         configured[dev] = true;
     }
     const int nqb = (Tq + 31) >> 5;
-    hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)B * 8 * nqb), dim3(64 * ATT_WAVES), lds, s, qkv, T, Tq, koff, Tk, nqb, out);
+    hipLaunchKernelGGL(attention_mfma_kernel<D>, dim3((unsigned)B * 8 * nqb), dim3(64 * ATT_WAVES), lds, s, q, q_ld, q_bstride, k, v, kv_ld, T, Tq,
+                       Tk, nqb, out);
     return hipGetLastError();
+}
+hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s) {
+    return launch_attention_any<128>(qkv, 3 * 1024, T, qkv + (size_t)koff * 3072 + 1024, qkv + (size_t)koff * 3072 + 2048, 3 * 1024, B, T, Tq, Tk, out, s);
 }
 
 // ------------------------------------------------------------------ learnable-query fusion
@@ -802,7 +819,7 @@ hipError_t launch_add_pe(const float *x, int ldx, int rows, int T, int d, const 
     return hipGetLastError();
 }
 
-// Attention with 256-wide heads (layers.py:241, 284-291).  No release config selects this fusion, so the kernel is the
+// Attention with 256-wide heads (layers.py:241, 284-291): the round-2 kernel, kept as the A/B reference of the MFMA one.  The
 // plain wave-per-query-row form: a lane owns 4 of the 256 head dimensions (one 16-byte vector), a score is a wave
 // reduction, softmax runs online (running max / sum are wave-uniform), K and V rows stream from L2 as 1 KiB wave loads.
 // Four query rows share each K / V row load.
@@ -845,6 +862,9 @@ __global__ __launch_bounds__(256) void attention_d256_kernel(const float *__rest
 hipError_t launch_attention_d256(const float *q, int q_ld, int q_bstride, const float *k, const float *v, int kv_ld, int B, int T,
                                  int Tq, float *out, hipStream_t s) {
     if (T <= 0 || Tq <= 0) return hipErrorInvalidValue;
+    // QK^T and PV on the fp32 matrix cores like the 128-wide heads (the same kernel template, D = 256); HMV_LQ_SCALAR_ATT=1
+    // keeps the wave-per-query-row form below (A/B runs, read per launch)
+    if (!getenv("HMV_LQ_SCALAR_ATT")) return launch_attention_any<256>(q, q_ld, q_bstride, k, v, kv_ld, B, T, Tq, T, out, s);
     hipLaunchKernelGGL(attention_d256_kernel, dim3(B * 8), dim3(256), 0, s, q, q_ld, q_bstride, k, v, kv_ld, T, Tq, out);
     return hipGetLastError();
 }

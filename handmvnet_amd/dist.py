@@ -41,6 +41,8 @@ class ResultGatherer:
         self.collectives = 0   # all-gathers issued so far (the gloo test holds this to one per step)
 
     def gather(self, local: Dict[str, torch.Tensor], total: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """With equal shards the returned tensors are VIEWS of the receive buffer, valid until the next gather (a timed loop
+        allocates nothing); gather_outputs() hands out copies."""
         cam, img = local["joints_cam"], local["joints_crop_img"]
         n = cam.shape[0]
         assert n <= self.n_max and img.shape[0] == n, "local shard larger than the gatherer was built for"
@@ -92,7 +94,7 @@ def gather_outputs(local: Dict[str, torch.Tensor], total: Optional[int] = None, 
     else:
         n_max = max(b_ - a_ for a_, b_ in (shard_range(total, r, world) for r in range(world)))
     out = gatherer_for(n_max, views, local["joints_cam"].device, group).gather(local, total)
-    return {k: out[k] for k in keys}
+    return {k: out[k].clone() for k in keys}   # the caller may keep these across later gathers
 
 
 def forward_sharded(model, x: torch.Tensor, bbox=None, cam_params=None, group=None) -> Dict[str, torch.Tensor]:

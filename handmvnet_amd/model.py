@@ -337,6 +337,16 @@ class HandMvNet(torch.nn.Module):
         _lib.check(_lib.load().hmv_read_stage(h, name.encode(), out.data_ptr(), out.numel(), ctypes.c_void_p(stream)), h)
         return out
 
+    def launch_count(self) -> int:
+        """Device operations (kernels, memsets, copies) enqueued by the last eager forward."""
+        hh, ww, idx, _, dt = self._last_key
+        return int(_lib.load().hmv_launch_count(self._engines[(hh, ww, idx, dt)]))
+
+    def set_tail_fusion(self, enable: bool = True):
+        """Fused tail kernels on (default) / off (the launch-per-op path) for the engines built so far (A/B, tests)."""
+        for h in self._engines.values():
+            _lib.check(_lib.load().hmv_set_tail_fusion(h, int(enable)), h)
+
     def poison_workspace(self, value: int = 0xFF):
         """Test hook: fills the workspace of the engine the last forward ran on with `value` bytes (0xFF = NaN patterns)."""
         hh, ww, idx, _, dt = self._last_key

@@ -100,6 +100,11 @@ size_t hmv_workspace_bytes(hmv_handle h, int32_t batch);
  * call it up front to keep allocation out of a timed or graph-captured region. */
 int hmv_reserve(hmv_handle h, int32_t batch);
 
+/* Fused tail kernels (fusion_kernels.hip: FeedForward + LayerNorms behind the to_out GEMM as one launch, the ChebConv decoder
+ * as two) on (default) or off (the launch-per-op path; also HMV_NO_FFFUSE=1 / HMV_NO_CHEBFUSE=1 at hmv_create time).  A/B runs
+ * and the equivalence test; the workspace is re-planned on the next forward. */
+int hmv_set_tail_fusion(hmv_handle h, int32_t enable);
+
 /* Test hook: fills the reserved workspace with the byte `value` (0xFF: NaNs) on `stream`.  No stage may read workspace bytes that
  * an earlier stage of the SAME forward has not written, so a forward after poisoning returns the bits of one before it. */
 int hmv_poison_workspace(hmv_handle h, int32_t value, void *stream);
@@ -142,6 +147,9 @@ int hmv_profile_get(hmv_handle h, int32_t index, const char **name, const char *
 /* algorithmic HBM bytes of that launch: input pixels, weights, residual and output rows each moved once in the storage type of
  * the arithmetic mode (what bench.py prices the launch's HBM roofline with). */
 int hmv_profile_get_bytes(hmv_handle h, int32_t index, double *bytes);
+/* Device operations (kernel launches, memsets, device-to-device copies) that the last eagerly run forward of this handle
+ * enqueued: the "launches per forward" figure of bench.py (a hipGraph replay enqueues ONE graph of as many nodes). */
+int hmv_launch_count(hmv_handle h);
 
 /* One NHWC convolution through the engine's conv kernel (op-level parity tests).
  * in [N][H][W][Cin] device; weight OIHW host (Cin must be a multiple of 4);
@@ -158,8 +166,9 @@ int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, int32_t N, 
                      int32_t pad, const float *residual, int32_t relu, float *out, void *stream);
 
 /* The fp16-storage op with fp16 OUTPUT rows (what a backbone layer of the fp16 path writes): out_f16 device [N][Ho][Wo][Cout]
- * halfs.  kernel_sel: 0 = the launcher's choice, 1 = conv_igemm only, 2 = the persistent weight-stationary kernel
- * (conv_stream.hip) wherever the shape has an instantiation.  *kernel_name (optional) receives the family that ran. */
+ * halfs.  kernel_sel: 0 = the launcher's choice, 1 = conv_igemm only, 2 = the round-3 kernels (conv_stream.hip: persistent
+ * weight-stationary residual 1x1; conv_gemm8.hip: phase-interleaved 256 x 256 1x1) wherever the shape has one, whatever its
+ * size.  *kernel_name (optional) receives the family that ran. */
 int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
                       const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
                       int32_t pad, const float *residual, int32_t relu, void *out_f16, int32_t kernel_sel,
@@ -170,6 +179,13 @@ int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int32_t H, int
  * tokens [koff, koff + Tk); out device [B][Tq][1024]. */
 int hmv_op_attention(int32_t device, const float *qkv, int32_t B, int32_t T, int32_t Tq, int32_t koff, int32_t Tk, float *out,
                      void *stream);
+
+/* The attention of the learnable-query fusion (MultiHeadAttentionLearnableQuery, layers.py:284-291; 8 heads x 256) through the
+ * engine's kernel: q rows at q + (b * q_bstride + i) * q_ld (q_bstride = 0: the same probe queries for every sample), k / v rows
+ * at k + (b * T + j) * kv_ld, j < T; softmax(q k^T / 16) v per (sample, head); out device [B][Tq][2048].  HMV_LQ_SCALAR_ATT=1 in
+ * the environment selects the non-MFMA kernel (A/B). */
+int hmv_op_attention_lq(int32_t device, const float *q, int32_t q_ld, int32_t q_bstride, const float *k, const float *v, int32_t kv_ld,
+                        int32_t B, int32_t T, int32_t Tq, float *out, void *stream);
 
 /* Diagnostic micro-benchmark: average milliseconds of `iters` launches of one NHWC conv shape on
  * pseudo-random data.  tile: -1 = the engine's own choice, else 0..7 = 128x32, 128x64, 128x128, 256x128,

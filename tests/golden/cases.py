@@ -42,6 +42,12 @@ CASES = {
                    fusion="cross_attn_learnable_query"),
     "r18_lq_wocam": dict(bt="18", ch=[256, 128, 64], V=2, B=1, size=64, pos=["pos2d"], gcn=False, wseed=22, iseed=32,
                          fusion="cross_attn_learnable_query"),
+    # HRNet-w40 (4 sampled levels, d = 300 + 12) with the learnable-query fusion: the configuration family in which round 2's probe
+    # saw the engine 2e-2 from the f64 oracle (profiles/r02_probe_lq_conditioning.txt); no LayerNorm around the attention, so the
+    # activations reach several hundred and the softmax is near one-hot (profiles/r03_probe_lq_hr40.txt: a 1e-7 input perturbation
+    # moves `fused` by as much in exact arithmetic)
+    "hr40_lq": dict(bt="w40", ch=[40, 80, 160, 320], V=2, B=1, size=64, pos=ALL_POS, gcn=True, wseed=31, iseed=41,
+                    fusion="cross_attn_learnable_query", cond=True),
     # frame sizes that are not multiples of 32 (the reference's convs take any size: resnet.py:216-254)
     "r50_200": dict(bt="50_paper", ch=[1024], V=2, B=1, size=200, pos=ALL_POS, gcn=True, wseed=23, iseed=33,
                     image_size=200, heatmap_size=25),

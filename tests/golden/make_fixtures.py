@@ -98,6 +98,47 @@ def run_case(name: str, spec: dict, check_oracle: bool = True) -> dict:
         fx[nm + "_shape"] = np.array(t.shape, dtype=np.int64)
         fx[nm + "_sum"] = np.float64(flat.astype(np.float64).sum())
         fx[nm + "_sqsum"] = np.float64((flat.astype(np.float64) ** 2).sum())
+    if spec.get("cond"):
+        # Conditioning of this configuration, measured on the reference's own fusion module in float64 (the decoder's ChebConv
+        # builds float32 Laplacian powers, layers.py:405-445, so it runs in fp32 on the float64 fusion output): by how much is a
+        # relative perturbation of the token matrix amplified into `fused` / joints_cam?  Where that factor is in the hundreds
+        # (learnable-query blocks on un-normalised HRNet features: no LayerNorm, softmax near one-hot; tools/lq_conditioning.py),
+        # no fp32 implementation can be held to the fixed parity tolerance; the tests then allow amplification x (the
+        # implementation's own token error) instead.
+        fus = model.joints_late_fusion
+        plain = []
+        fus.double()
+        for mod in fus.modules():   # plain float attributes (the PE table) do not follow .double()
+            for k, v in list(vars(mod).items()):
+                if torch.is_tensor(v) and v.dtype == torch.float32:
+                    plain.append((mod, k, v))
+                    setattr(mod, k, v.double())
+        is_lq = mp["fusion"] == "cross_attn_learnable_query"
+        call = (lambda t: fus(t)) if is_lq else (lambda t: fus(t, add_pos="sin" in mp["pos_enc"]))
+        rl = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        try:
+            with torch.no_grad():
+                t64 = stages["tokens"].double()
+                f64 = call(t64)
+                cam64 = model.joints_decoder(f64.float())
+                g = torch.Generator().manual_seed(7)
+                amp_f, amp_c = [], []
+                for eps in (1e-6, 1e-5):
+                    for _ in range(4):
+                        tp_ = t64 * (1.0 + eps * torch.randn(t64.shape, generator=g, dtype=torch.float64))
+                        fp_ = call(tp_)
+                        din = rl(tp_, t64)
+                        amp_f.append(rl(fp_, f64) / din)
+                        amp_c.append(rl(model.joints_decoder(fp_.float()), cam64) / din)
+        finally:
+            for mod, k, v in plain:
+                setattr(mod, k, v)
+            fus.float()
+        fx["cond_fused32_vs_64"] = np.float64(rl(stages["fused"], f64))   # the reference's own fp32 run vs its float64 fusion
+        fx["amp_fused"] = np.float64(max(amp_f))
+        fx["amp_joints_cam"] = np.float64(max(amp_c))
+        print(f"  conditioning: d(fused)/d(tokens) up to {fx['amp_fused']:.0f}, d(joints_cam)/d(tokens) up to {fx['amp_joints_cam']:.0f}; "
+              f"reference fp32 fused vs its float64 fusion {fx['cond_fused32_vs_64']:.3e}")
     if check_oracle:
         from oracle.oracle import Oracle
         for acc in ("f32", "f64"):

@@ -82,7 +82,13 @@ def rel(a, b):
 def main():
     torch.set_num_threads(8)
     res = {}
+    only = set(sys.argv[1:])   # `make_fp16_noise.py <case> ...`: measure these cases only and merge them into the existing file
+    if only:
+        with open(os.path.join(HERE, "fp16_noise.json")) as f:
+            res = json.load(f)["cases"]
     for name in CASES:
+        if only and name not in only:
+            continue
         cfg, ref = run(name, False)
         _, got = run(name, True)
         k = cfg.heatmap_size / cfg.image_size

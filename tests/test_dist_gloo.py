@@ -58,7 +58,18 @@ def _worker(rank, world, port, case, batch, q):
         model = _OracleModel(case)
         x, bbox, intr = synth_inputs(model.cfg, batch, 77, 64)
         xt, bt, it = torch.from_numpy(x), torch.from_numpy(bbox), torch.from_numpy(intr)
+        # count what the communicator is really asked to do: ONE packed all-gather per step, nothing else
+        calls = {"n": 0}
+        real = dist.all_gather_into_tensor
+
+        def counted(*a, **k):
+            calls["n"] += 1
+            return real(*a, **k)
+        dist.all_gather_into_tensor = counted
+        for forbidden in ("all_gather", "all_reduce", "broadcast", "all_to_all"):
+            setattr(dist, forbidden, lambda *a, _n=forbidden, **k: (_ for _ in ()).throw(AssertionError(f"unexpected collective {_n}")))
         out = forward_sharded(model, xt, bt, {"intrinsic": it})
+        assert calls["n"] == 1, calls
         # equal-shard fast path: gather a local result directly
         a, b = shard_range(batch, rank, world)
         if b > a:
@@ -66,7 +77,16 @@ def _worker(rank, world, port, case, batch, q):
         else:   # batch < world: this rank holds no sample and contributes zero rows to the collective
             local = {"joints_cam": torch.zeros(0, 21, 3), "joints_crop_img": torch.zeros(0, xt.shape[1], 21, 2)}
         g2 = gather_outputs(local, total=batch)
-        assert torch.equal(g2["joints_cam"], out["joints_cam"])
+        assert calls["n"] == 2, calls
+        assert torch.equal(g2["joints_cam"], out["joints_cam"]) and torch.equal(g2["joints_crop_img"], out["joints_crop_img"])
+        # the packed buffers are allocated once and reused: same gatherer, same storage, its own count agrees
+        from handmvnet_amd.dist import gatherer_for
+        n_max = max(b_ - a_ for a_, b_ in (shard_range(batch, r, world) for r in range(world)))
+        g = gatherer_for(n_max, xt.shape[1], xt.device)
+        assert g.collectives == 2 and g.send.shape == (n_max, 63 + 42 * xt.shape[1]) and g.recv.shape[0] == world * n_max
+        ptr = g.send.data_ptr()
+        g3 = gather_outputs(local, total=batch)
+        assert g.send.data_ptr() == ptr and g.collectives == 3 and torch.equal(g3["joints_cam"], out["joints_cam"])
         if rank == 0:
             q.put({k: v.numpy() for k, v in out.items()})
     finally:

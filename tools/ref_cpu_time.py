@@ -24,7 +24,7 @@ from handmvnet_amd.synth import synth_inputs, synth_state_dict  # noqa: E402
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-SHAPES = {"cfg3": 256, "cfg2": 256, "hr40": 256}
+SHAPES = {"cfg3": 256, "cfg2": 256, "hr40": 256, "cfg1": 128}   # cfg1 = BASELINE configs[0]: HO3D_HandMvNet.yaml, B1 x V4 x 128x128
 
 
 def main():

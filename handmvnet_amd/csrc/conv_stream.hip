@@ -47,6 +47,9 @@ typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
 #define HMV_SGLDS16(gptr, lptr)                                                                             \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+#define HMV_SGLDS16_NT(gptr, lptr)   /* aux = 2: non-temporal */                                            \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 2)
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -65,32 +68,40 @@ __device__ __forceinline__ void static_for(F &&f) {
 // ---- the static schedule.  A pixel tile is NP + 1 slots: slot j < NP = piece step j (PA pixel DMAs, and at j = 0 the RB residual
 // DMAs of the next tile behind them), slot NP = the epilogue (OS stores).  vector-memory instructions retire in issue order, so
 // "X has landed" == "at most (instructions issued after X) are still out".
-constexpr int sched_ops(int NP, int PA, int RB, int OS, int slot) { return slot < NP ? PA + (slot == 0 ? RB : 0) : OS; }
+// RS = residual DMAs issued at EVERY piece step (the spread schedule), 0 = all RB of them at step 0
+constexpr int sched_r(int RB, int RS, int j) { return RS ? RS : (j == 0 ? RB : 0); }
+constexpr int sched_ops(int NP, int PA, int RB, int RS, int OS, int slot) { return slot < NP ? PA + sched_r(RB, RS, slot) : OS; }
 // instructions issued after the pixel DMAs of piece (t, j) when step (t, j) begins; they went out at step index g - D
-constexpr int sched_after_piece(int NP, int D, int PA, int RB, int OS, int j) {
+constexpr int sched_after_piece(int NP, int D, int PA, int RB, int RS, int OS, int j) {
     const int T0 = 8, g = T0 * NP + j - D, tq = g / NP, jq = g - tq * NP;
-    int n = jq == 0 ? RB : 0;
-    for (int s = tq * (NP + 1) + jq + 1; s < T0 * (NP + 1) + j; ++s) n += sched_ops(NP, PA, RB, OS, s % (NP + 1));
+    int n = sched_r(RB, RS, jq);
+    for (int s = tq * (NP + 1) + jq + 1; s < T0 * (NP + 1) + j; ++s) n += sched_ops(NP, PA, RB, RS, OS, s % (NP + 1));
     return n;
 }
-// instructions issued after the residual DMAs of tile t (step (t - 1, 0)) when the epilogue of tile t begins
-constexpr int sched_after_residual(int NP, int PA, int RB, int OS) {
-    const int T0 = 8;
+// instructions issued after the LAST residual DMA of tile t (step (t - 1, 0), or (t - 1, NP - 1) when spread) when the epilogue of
+// tile t begins
+constexpr int sched_after_residual(int NP, int PA, int RB, int RS, int OS) {
+    const int T0 = 8, last = RS ? NP - 1 : 0;
     int n = 0;
-    for (int s = (T0 - 1) * (NP + 1) + 1; s < T0 * (NP + 1) + NP; ++s) n += sched_ops(NP, PA, RB, OS, s % (NP + 1));
+    for (int s = (T0 - 1) * (NP + 1) + last + 1; s < T0 * (NP + 1) + NP; ++s) n += sched_ops(NP, PA, RB, RS, OS, s % (NP + 1));
     return n;
 }
-static_assert(sched_after_piece(4, 3, 1, 8, 8, 0) == 10 && sched_after_piece(4, 3, 1, 8, 8, 1) == 18 && sched_after_piece(4, 3, 1, 8, 8, 2) == 18 &&
-              sched_after_piece(4, 3, 1, 8, 8, 3) == 10 && sched_after_residual(4, 1, 8, 8) == 23, "the K = 256 schedule, counted by hand");
+static_assert(sched_after_piece(4, 3, 1, 8, 0, 8, 0) == 10 && sched_after_piece(4, 3, 1, 8, 0, 8, 1) == 18 && sched_after_piece(4, 3, 1, 8, 0, 8, 2) == 18 &&
+              sched_after_piece(4, 3, 1, 8, 0, 8, 3) == 10 && sched_after_residual(4, 1, 8, 0, 8) == 23, "the K = 256 schedule, counted by hand");
+static_assert(sched_after_piece(4, 3, 1, 8, 2, 8, 0) == 2 + 3 + 3 + 8 && sched_after_residual(4, 1, 8, 2, 8) == 8 + 4 * 3, "the spread K = 256 schedule");
 
 // TM x TN 32x32 blocks per wave, MW x NW waves (pixels x channels), NP 64-channel pieces of reduction, NSLOT ring slots.
-template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES>
+// SPREAD: the next tile's residual DMAs go out RB / NP per piece step instead of all at step 0 (a smoother request stream);
+// NT: 0 default cache policy, 1 residual rows non-temporal (read once), 2 pixel pieces too
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool SPREAD = false, int NT_ = 0>
 __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(const ConvParams p) {
     constexpr int NWV = MW * NW, NT = 64 * NWV;
     constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW;
     constexpr int D = NSLOT - 1;                 // pieces in flight ahead of the one being consumed
     constexpr int PA = BM * 8 / NT;              // pixel DMA instructions per piece and thread (a piece row = 8 x 16 bytes)
     constexpr int RB = HAS_RES ? TM * TN * 2 : 0, OS = TM * TN * 2;
+    constexpr int RS = (SPREAD && HAS_RES) ? RB / NP : 0;
+    static_assert(!SPREAD || RB % NP == 0, "spread schedule: whole residual DMAs per step");
     constexpr int ZW = TM * TN * 2 * 1024;       // bytes of one wave's residual landing zone
     constexpr int NFAKE = (D + NP - 1) / NP;     // tiles "before the first" whose schedule the prologue replays
     static_assert(NT == 512 && BM % 64 == 0 && PA >= 1, "eight waves; whole DMA passes per piece");
@@ -145,39 +156,43 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
             const bool ok = tt >= 0 && tt < ntl && m < p.M;
             const _Float16 *src = ok ? Ain + (size_t)m * p.lda + jj * 64 + 8 * kqs : zero16;
             asm volatile("" : "+v"(src));   // ONE DMA instruction per schedule entry: keep the select out of the control flow
-            HMV_SGLDS16(src, sA + ((slot * BM + i * 64 + wave * 8) * 64));
+            if constexpr (NT_ >= 2) HMV_SGLDS16_NT(src, sA + ((slot * BM + i * 64 + wave * 8) * 64));
+            else HMV_SGLDS16(src, sA + ((slot * BM + i * 64 + wave * 8) * 64));
         }
     };
     // issue the residual DMAs of tile tt: every lane fetches ITS OWN 8 channels of its own pixel, lane-linear landing zone
-    auto issue_R = [&](int tt) {
+    // (instruction idx = (a * TN + b) * 2 + j; `first` .. `first + count` go out in this call)
+    auto issue_R = [&](int tt, auto first_c, auto count_c) {
         if constexpr (HAS_RES) {
+            constexpr int first = decltype(first_c)::value, count = decltype(count_c)::value;
             const int mt = stream + tt * nstreams;
             char *z = zones + ((tt & 1) * NWV + wave) * ZW;
 #pragma unroll
-            for (int a = 0; a < TM; ++a) {
+            for (int idx = first; idx < first + count; ++idx) {
+                const int a = idx / (2 * TN), b = (idx / 2) % TN, j = idx & 1;
                 const int m = mt * BM + (mw * TM + a) * 32 + l31;
                 const bool ok = tt >= 0 && tt < ntl && m < p.M;
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const _Float16 *src = ok ? Rin + (size_t)m * p.ldr + n0 + 32 * b + 16 * j + 8 * kh : zero16;
-                        asm volatile("" : "+v"(src));
-                        HMV_SGLDS16(src, z + ((a * TN + b) * 2 + j) * 1024);
-                    }
+                const _Float16 *src = ok ? Rin + (size_t)m * p.ldr + n0 + 32 * b + 16 * j + 8 * kh : zero16;
+                asm volatile("" : "+v"(src));
+                if constexpr (NT_ >= 1) HMV_SGLDS16_NT(src, z + idx * 1024);
+                else HMV_SGLDS16(src, z + idx * 1024);
             }
         }
     };
+    using I0 = std::integral_constant<int, 0>;
+    using IRB = std::integral_constant<int, RB>;
+    using IRS = std::integral_constant<int, RS>;
 
     // ---- prologue: the schedule of the NFAKE tiles before the first, with every instruction it would have issued
     // (real ones where they belong to tile 0 .., dummies otherwise), so that the counted waits hold from tile 0 on
 #pragma unroll
     for (int ft = -NFAKE; ft < 0; ++ft) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
+        static_for<NP>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             issue_A(ft * NP + j + D);
-            if (j == 0) issue_R(ft + 1);
-        }
+            if constexpr (RS > 0) issue_R(ft + 1, std::integral_constant<int, j * RS>{}, IRS{});
+            else if constexpr (j == 0) issue_R(ft + 1, I0{}, IRB{});
+        });
 #pragma unroll
         for (int i = 0; i < OS; ++i)   // inline asm: identical stores to one address must not be merged away
             asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(trash), "v"(sf32x4{0.f, 0.f, 0.f, 0.f}) : "memory");
@@ -208,10 +223,11 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
             }
         static_for<NP>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            wait_vm<sched_after_piece(NP, D, PA, RB, OS, j)>();                                       // my share of piece (tt, j) has landed
+            wait_vm<sched_after_piece(NP, D, PA, RB, RS, OS, j)>();                                   // my share of piece (tt, j) has landed
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // everyone's has; everyone is done with piece g - 1
             issue_A(tt * NP + j + D);                                            // ... whose slot takes piece g + D
-            if constexpr (j == 0) issue_R(tt + 1);
+            if constexpr (RS > 0) issue_R(tt + 1, std::integral_constant<int, j * RS>{}, IRS{});
+            else if constexpr (j == 0) issue_R(tt + 1, I0{}, IRB{});
             const _Float16 *pa = sA + ((((tt * NP + j) & (NSLOT - 1)) * BM + mw * TM * 32 + l31) * 64);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -226,7 +242,7 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
             }
         });
         // ---- epilogue: acc (+ residual) -> relu -> fp16, 16-byte stores of 8 consecutive channels
-        if constexpr (HAS_RES) wait_vm<sched_after_residual(NP, PA, RB, OS)>();
+        if constexpr (HAS_RES) wait_vm<sched_after_residual(NP, PA, RB, RS, OS)>();
         const int mt = stream + tt * nstreams;
         const char *z = zones + ((tt & 1) * NWV + wave) * ZW + lane * 16;
 #pragma unroll
@@ -254,13 +270,13 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
 }
 
 // ====================================================================== host side
-template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES>
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool SPREAD = false, int NT_ = 0>
 static hipError_t launch_stream_one(ConvParams p, hipStream_t s) {
     constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW, NWV = MW * NW;
     constexpr size_t lds = (size_t)NSLOT * BM * 128 + (HAS_RES ? (size_t)2 * NWV * TM * TN * 2 * 1024 : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool configured[64] = {};
-    auto kern = conv_stream_f16<TM, TN, MW, NW, NP, NSLOT, HAS_RES>;
+    auto kern = conv_stream_f16<TM, TN, MW, NW, NP, NSLOT, HAS_RES, SPREAD, NT_>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
@@ -305,18 +321,35 @@ bool conv_stream_supported(const ConvParams &p) {
 }
 
 hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **name) {
+    // development knob (A/B runs): HMV_STREAM_VARIANT = 0 residual DMAs at step 0, 1 spread over the piece steps, 2 / 3 the same with
+    // non-temporal residual loads, 4 non-temporal pixel pieces too.  Measured (profiles/r03_probe_stream_variants.txt): spreading
+    // gains 3-4 % at K = 256 (four piece steps) and loses 4 % at K = 128; non-temporal loads lose 15-25 % everywhere (the next
+    // launch finds less of its input in the Infinity Cache).  Default: spread at K = 256 only.
+    static int variant = -1;
+    if (variant < 0) { const char *e = getenv("HMV_STREAM_VARIANT"); variant = e ? atoi(e) : -1; if (variant < 0) variant = 100; }
+#define HMV_STREAM_VARIANTS(...)                                                                            \
+    switch (variant) {                                                                                      \
+        case 1: return launch_stream_one<__VA_ARGS__, true, true, 0>(p, s);                                 \
+        case 2: return launch_stream_one<__VA_ARGS__, true, false, 1>(p, s);                                \
+        case 3: return launch_stream_one<__VA_ARGS__, true, true, 1>(p, s);                                 \
+        case 4: return launch_stream_one<__VA_ARGS__, true, true, 2>(p, s);                                 \
+        case 100: if (p.Kpad == 256) return launch_stream_one<__VA_ARGS__, true, true, 0>(p, s);            \
+                  return launch_stream_one<__VA_ARGS__, true, false, 0>(p, s);                              \
+        default: return launch_stream_one<__VA_ARGS__, true, false, 0>(p, s);                               \
+    }
     if (p.Kpad == 256) {
         if (name) *name = "conv_stream_f16<64x512,k256,res>";
-        return launch_stream_one<2, 2, 1, 8, 4, 4, true>(p, s);
+        HMV_STREAM_VARIANTS(2, 2, 1, 8, 4, 4)
     }
     if (p.Kpad == 128) {
         if (name) *name = "conv_stream_f16<64x512,k128,res>";
-        return launch_stream_one<2, 2, 1, 8, 2, 4, true>(p, s);
+        HMV_STREAM_VARIANTS(2, 2, 1, 8, 2, 4)
     }
     if (p.Kpad == 64) {
         if (name) *name = "conv_stream_f16<128x256,k64,res>";
-        return launch_stream_one<2, 2, 2, 4, 1, 2, true>(p, s);
+        HMV_STREAM_VARIANTS(2, 2, 2, 4, 1, 2)
     }
+#undef HMV_STREAM_VARIANTS
     return hipErrorInvalidValue;
 }
 

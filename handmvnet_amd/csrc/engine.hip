@@ -1173,7 +1173,7 @@ struct Runner {
     bool ff_fusable(const Layer &out, const Layer &ff1, const Layer &ff2, int rows, int ldt) const {
         return h->ff_fuse && splitk_slices(out, rows) > 1 && !ff1.f16 && !ff2.f16 && !ff1.plane && !ff2.plane &&
                ff1.Kpad == ldt && ldt % 16 == 0 && (ff1.Cout == 128 || ff1.Cout == 256) && ff2.Kpad == ff1.Cout && ff2.Cout_pad >= ldt &&
-               ldt <= 1024;
+               ldt <= 576;
     }
     void ff_block(const Layer &out, const Layer &ff1, const Layer &ff2, const float *att, int rows, const float *res, int ldr, int rg_out,
                   int rg_in, const float *n1g, const float *n1b, const float *fg, const float *fb, const float *n2g, const float *n2b,
@@ -1193,6 +1193,20 @@ struct Runner {
             p.n1g = n1g; p.n1b = n1b; p.fg = fg; p.fb = fb; p.n2g = n2g; p.n2b = n2b;
             p.w1 = ff1.w; p.b1 = ff1.bias; p.ldw1 = ff1.Kpad; p.w2 = ff2.w; p.b2 = ff2.bias; p.ldw2 = ff2.Kpad;
             p.out = y; p.ldo = ldt; p.hid = ff1.Cout;
+            static unsigned long long *ffdbg = nullptr;   // HMV_FF_DBG=1: phase stamps of the last launch, printed by the next one
+            if (getenv("HMV_FF_DBG")) {
+                if (!ffdbg) (void)hipMalloc(reinterpret_cast<void **>(&ffdbg), 4096 * 64);
+                else {
+                    unsigned long long hst[8 * 4];
+                    (void)hipStreamSynchronize(s);
+                    (void)hipMemcpy(hst, ffdbg, sizeof(hst), hipMemcpyDeviceToHost);
+                    for (int w = 0; w < 2; ++w)
+                        fprintf(stderr, "[ff_block wg %d] phase0 %.2f us  gemm1 %.2f  gemm2 %.2f  ln2+store %.2f  (entry->exit %.2f us)\n", w * 3,
+                                (hst[w * 24 + 1] - hst[w * 24]) * 0.01, (hst[w * 24 + 2] - hst[w * 24 + 1]) * 0.01, (hst[w * 24 + 3] - hst[w * 24 + 2]) * 0.01,
+                                (hst[w * 24 + 4] - hst[w * 24 + 3]) * 0.01, (hst[w * 24 + 4] - hst[w * 24]) * 0.01);
+                }
+                p.dbg = ffdbg;
+            }
             check(launch_ff_block(p, s), "ff_block");
             ++h->launches;
         }

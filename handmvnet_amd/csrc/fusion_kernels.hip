@@ -34,178 +34,279 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + er
 
 constexpr int FF_ROWS = 16;          // token rows per workgroup
 constexpr int FF_WAVES = 8;
-constexpr int FF_MAX_PER_LANE = 16;  // d <= 1024, as launch_layernorm
+// (the kernel runs ONCE per wave: its straight-line code is kept short -- 48 KB of unrolled code cost more in cold instruction
+// fetches than the arithmetic it held)
 
-// one 16 x 16 output block: A[16][K] (LDS, row stride lda) . W[16 rows of n][K]^T (global, row stride ldw), K % 16 == 0.
-// The weight vectors of the NEXT 64-wide chunk are in flight while this chunk's 16 MFMAs run (an L2 round trip per chunk would
-// otherwise cost more than the MFMAs); two accumulators alternate so that the chain is issue-bound, not latency-bound.
-__device__ __forceinline__ ff32x4 mfma_block_16(const float *sa, int lda, const float *w, int ldw, int K, int lane) {
-    const int r = lane & 15, g = lane >> 4;
-    const float *ap = sa + r * lda + 4 * g;
-    const float *wp = w + (size_t)r * ldw + 4 * g;
+// One 16 x 16 output block = A[16][K] (LDS, row stride lda) . W[16 rows of n][K]^T (global, row stride ldw), K = 16 nv.
+// The weight vectors of a block do not depend on the activations, so they are requested in ONE burst (wload) as early as the
+// registers allow -- ahead of the LayerNorm phase for the first GEMM -- and the block is then 4 nv back-to-back MFMAs (wmma): a
+// launch-bound kernel must not pay an L2 round trip per 64 columns.  Two accumulators alternate (issue-bound, not latency-bound).
+template <int NV>
+__device__ __forceinline__ void wload(ff32x4 (&b)[NV], const float *w, int ldw, int nv, int lane) {
+    const float *wp = w + (size_t)(lane & 15) * ldw + 4 * (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+        if (s < nv) b[s] = *reinterpret_cast<const ff32x4 *>(wp + 16 * s);
+}
+template <int NV>
+__device__ __forceinline__ ff32x4 wmma(const float *sa, int lda, const ff32x4 (&b)[NV], int nv, int lane) {
+    const float *ap = sa + (lane & 15) * lda + 4 * (lane >> 4);
     ff32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int nfull = K >> 6;
-    ff32x4 b0[4], b1[4];
-    if (nfull > 0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) b0[u] = *reinterpret_cast<const ff32x4 *>(wp + 16 * u);
-    }
-    for (int c = 0; c < nfull; ++c) {
-        const int s = c << 6;
-        if (c + 1 < nfull) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) b1[u] = *reinterpret_cast<const ff32x4 *>(wp + s + 64 + 16 * u);
+    for (int s = 0; s < NV; ++s)
+        if (s < nv) {
+            const ff32x4 a = *reinterpret_cast<const ff32x4 *>(ap + 16 * s);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[s][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[s][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[s][2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[s][3], acc1, 0, 0, 0);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const ff32x4 a = *reinterpret_cast<const ff32x4 *>(ap + s + 16 * u);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0[u][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b0[u][1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b0[u][2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b0[u][3], acc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) b0[u] = b1[u];
-    }
-    for (int s = nfull << 6; s < K; s += 16) {
-        const ff32x4 a = *reinterpret_cast<const ff32x4 *>(ap + s);
-        const ff32x4 b = *reinterpret_cast<const ff32x4 *>(wp + s);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
-    }
     return acc0 + acc1;   // lane holds D[4 g + e][r], e = 0..3
 }
+constexpr int FF_NV1 = 36;   // ld <= 576: the 16-wide steps of the first GEMM's reduction
+constexpr int FF_NV2 = 16;   // hid <= 256
 
-// LayerNorm of one row held as v[i] = x[lane + 64 i] (zeros past d), the arithmetic of layernorm_kernel (misc_kernels.hip)
-__device__ __forceinline__ void ln_row(float (&v)[FF_MAX_PER_LANE], int d, int lane, const float *g, const float *b) {
-    float s = 0.f;
+// A lane owns the 16-byte column groups c = 4 lane + 256 i (+ 0..3), i < FF_VEC: rows move as 16-byte vectors (a third of the
+// load instructions of a column-per-lane layout: the kernel's phase 0 is bound by how many loads it has to issue and retire).
+constexpr int FF_VEC = 3;            // ld <= 768
+// LayerNorm of the wave's TWO rows (zeros past d), the arithmetic of layernorm_kernel (misc_kernels.hip); gamma / beta arrive in
+// registers (requested at kernel entry: a load behind the reductions would add a round trip per LayerNorm), the two rows'
+// reductions interleave
+__device__ __forceinline__ void ln_rows2(ff32x4 (&v)[2][FF_VEC], int d, int lane, const float *sg, const float *sb) {
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < FF_MAX_PER_LANE; ++i) s += v[i];
-    const float inv_d = 1.f / (float)d, mean = fwave_sum(s) * inv_d;
-    float q = 0.f;
+    for (int i = 0; i < FF_VEC; ++i)
 #pragma unroll
-    for (int i = 0; i < FF_MAX_PER_LANE; ++i) {
-        const float t = (lane + 64 * i) < d ? v[i] - mean : 0.f;
-        q += t * t;
-    }
-    const float rstd = 1.f / sqrtf(fwave_sum(q) * inv_d + 1e-5f);
+        for (int e = 0; e < 4; ++e) { s0 += v[0][i][e]; s1 += v[1][i][e]; }
+    const float inv_d = 1.f / (float)d;
+    const float m0 = fwave_sum(s0) * inv_d, m1 = fwave_sum(s1) * inv_d;
+    float q0 = 0.f, q1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < FF_MAX_PER_LANE; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = c < d ? (v[i] - mean) * rstd * g[c] + b[c] : 0.f;
+    for (int i = 0; i < FF_VEC; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool in = (4 * lane + 256 * i + e) < d;
+            const float t0 = in ? v[0][i][e] - m0 : 0.f, t1 = in ? v[1][i][e] - m1 : 0.f;
+            q0 += t0 * t0;
+            q1 += t1 * t1;
+        }
+    const float r0 = 1.f / sqrtf(fwave_sum(q0) * inv_d + 1e-5f), r1 = 1.f / sqrtf(fwave_sum(q1) * inv_d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < FF_VEC; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c >= d) continue;
+        // gamma / beta from the workgroup's LDS copy (staged up to ld >= round4(d), zeros past d)
+        const ff32x4 g = *reinterpret_cast<const ff32x4 *>(sg + c), b = *reinterpret_cast<const ff32x4 *>(sb + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool in = (c + e) < d;
+            v[0][i][e] = in ? (v[0][i][e] - m0) * r0 * g[e] + b[e] : 0.f;
+            v[1][i][e] = in ? (v[1][i][e] - m1) * r1 * g[e] + b[e] : 0.f;
+        }
     }
 }
+// barrier for LDS hand-offs only: __syncthreads() also drains the vector-memory queue, i.e. it would wait for the weight vectors
+// that are deliberately left in flight across it
+#define FF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// HID = hidden width of the FeedForward: 128 (fusion.py:7-30) or 256 (the learnable-query blocks)
+template <int HID>
 __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockParams p) {
+    static_assert(FF_ROWS == 2 * FF_WAVES, "a wave owns two token rows");
+    constexpr int NV2 = HID / 16;            // 16-wide reduction steps of the second GEMM
+    constexpr int NB2 = 5;                   // column blocks of the second GEMM per wave: ceil(36 / 8)
+    constexpr bool ALL2 = HID == 128;        // 128-wide hidden layer: all of a wave's W2 vectors fit the registers W1 vacates
     extern __shared__ __attribute__((aligned(16))) float fsm[];
-    const int LD = p.ld + 4, LH = p.hid + 4;
+    const int LD = p.ld + 4, LH = HID + 4;
     float *sN = fsm;                   // [16][LD]  n1 (the FeedForward's residual)
     float *sF = sN + FF_ROWS * LD;     // [16][LD]  f0, later f2
     float *sH = sF + FF_ROWS * LD;     // [16][LH]  hidden activations
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * FF_ROWS;
-
-    // ---- phase 0: assemble the pre-norm rows, LayerNorm1, the FeedForward's LayerNorm (wave w: rows 2w, 2w + 1)
+    unsigned long long stamp[6] = {};
+    if (p.dbg) stamp[0] = __builtin_amdgcn_s_memrealtime();
+    // nothing below depends on the activations: requested first, in flight while the rows are assembled and normalised
+    ff32x4 wv1[FF_NV1];
+    const int nv1 = p.ld >> 4, nblk2 = p.ld >> 4;
+    wload(wv1, p.w1 + (size_t)wave * 16 * p.ldw1, p.ldw1, nv1, lane);
+    // the three LayerNorms' gamma / beta: staged once per workgroup ([6][ld] floats behind the activation tiles)
+    float *sP = sH + FF_ROWS * LH;
+    {
+        const float *src[6] = {p.n1g, p.n1b, p.fg, p.fb, p.n2g, p.n2b};
+        float t[6][2];   // ld <= 768 < 2 x 512 threads: every load is issued before the first store
 #pragma unroll
-    for (int rr = 0; rr < FF_ROWS / FF_WAVES; ++rr) {
-        const int lr = wave * (FF_ROWS / FF_WAVES) + rr;
-        const int row = min(row0 + lr, p.rows - 1);
-        const float *res = nullptr;
-        if (p.res) res = p.res + (size_t)(p.rg_out ? (row / p.rg_out) * p.rg_in + (row % p.rg_out) : row) * p.ldr;
-        float v[FF_MAX_PER_LANE];
+        for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int i = 0; i < FF_MAX_PER_LANE; ++i) {
-            const int c = lane + 64 * i;
-            if (64 * i >= p.d) { v[i] = 0.f; continue; }   // wave-uniform
-            const int cc = c < p.d ? c : 0;
-            float t;
-            if (p.slab) {   // slices added in index order, then bias, then the residual: the arithmetic of splitk_reduce_kernel
-                t = 0.f;
-                for (int k = 0; k < p.S; ++k) t += p.slab[k * p.slice + (size_t)row * p.lds + cc];
-                t += p.bias0[cc];
-                if (res) t += res[cc];
-            } else {
-                t = p.x[(size_t)row * p.ldx + cc];
+            for (int u = 0; u < 2; ++u) {
+                const int c = tid + 64 * FF_WAVES * u;
+                t[a][u] = (src[a] && c < p.d) ? src[a][c] : 0.f;
             }
-            v[i] = c < p.d ? t : 0.f;
-        }
-        if (p.n1g) ln_row(v, p.d, lane, p.n1g, p.n1b);
 #pragma unroll
-        for (int i = 0; i < FF_MAX_PER_LANE; ++i) {
-            const int c = lane + 64 * i;
-            if (c < p.ld) sN[lr * LD + c] = v[i];
-        }
-        ln_row(v, p.d, lane, p.fg, p.fb);
+        for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int i = 0; i < FF_MAX_PER_LANE; ++i) {
-            const int c = lane + 64 * i;
-            if (c < p.ld) sF[lr * LD + c] = v[i];
-        }
+            for (int u = 0; u < 2; ++u) {
+                const int c = tid + 64 * FF_WAVES * u;
+                if (c < p.ld) sP[a * p.ld + c] = t[a][u];
+            }
     }
-    __syncthreads();
+    FF_BARRIER();
+
+    // ---- phase 0: assemble the pre-norm rows, LayerNorm1, the FeedForward's LayerNorm (wave w: rows 2w, 2w + 1, together)
+    {
+        ff32x4 v[2][FF_VEC];
+        const int dv = (p.d + 3) & ~3;   // rows are readable up to round4(d): every row stride is a multiple of 4
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = min(row0 + 2 * wave + r, p.rows - 1);
+            const float *res = nullptr;
+            if (p.res) res = p.res + (size_t)(p.rg_out ? (row / p.rg_out) * p.rg_in + (row % p.rg_out) : row) * p.ldr;
+#pragma unroll
+            for (int i = 0; i < FF_VEC; ++i) {
+                const int c = 4 * lane + 256 * i;
+                v[r][i] = ff32x4{0.f, 0.f, 0.f, 0.f};
+                if (256 * i >= p.d) continue;   // wave-uniform
+                const int cc = c < dv ? c : 0;
+                ff32x4 t;
+                if (p.slab) {   // slices added in index order, then bias, then the residual: the arithmetic of splitk_reduce_kernel
+                    // (every load is issued before anything is added: a runtime-bounded loop here costs S dependent round trips)
+                    ff32x4 part[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) part[k] = *reinterpret_cast<const ff32x4 *>(p.slab + (k < p.S ? k : 0) * p.slice + (size_t)row * p.lds + cc);
+                    const ff32x4 bb = *reinterpret_cast<const ff32x4 *>(p.bias0 + cc);
+                    ff32x4 rv = {0.f, 0.f, 0.f, 0.f};
+                    if (res) rv = *reinterpret_cast<const ff32x4 *>(res + cc);
+                    t = ff32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < p.S) t += part[k];
+                    t += bb;
+                    if (res) t += rv;
+                } else {
+                    t = *reinterpret_cast<const ff32x4 *>(p.x + (size_t)row * p.ldx + cc);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[r][i][e] = (c + e) < p.d ? t[e] : 0.f;
+            }
+        }
+        if (p.n1g) ln_rows2(v, p.d, lane, sP, sP + p.ld);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < FF_VEC; ++i) {
+                const int c = 4 * lane + 256 * i;
+                if (c < p.ld) *reinterpret_cast<ff32x4 *>(&sN[(2 * wave + r) * LD + c]) = v[r][i];
+            }
+        ln_rows2(v, p.d, lane, sP + 2 * p.ld, sP + 3 * p.ld);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < FF_VEC; ++i) {
+                const int c = 4 * lane + 256 * i;
+                if (c < p.ld) *reinterpret_cast<ff32x4 *>(&sF[(2 * wave + r) * LD + c]) = v[r][i];
+            }
+    }
+    FF_BARRIER();
+    if (p.dbg) stamp[1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 1: h = GELU(f0 W1^T + b1), 16-column blocks dealt to the waves
     const int r16 = lane & 15, g4 = lane >> 4;
-    for (int nb = wave; nb < p.hid / 16; nb += FF_WAVES) {
-        const ff32x4 acc = mfma_block_16(sF, LD, p.w1 + (size_t)nb * 16 * p.ldw1, p.ldw1, p.ld, lane);
-        const int col = nb * 16 + r16;
-        const float bb = p.b1[col];
+    ff32x4 w2all[ALL2 ? NB2 : 1][NV2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sH[(4 * g4 + e) * LH + col] = gelu_erf(acc[e] + bb);
+    for (int u = 0; u < HID / 16 / FF_WAVES; ++u) {
+        const int nb = wave + FF_WAVES * u;
+        if (u > 0) wload(wv1, p.w1 + (size_t)nb * 16 * p.ldw1, p.ldw1, nv1, lane);   // (256-wide hidden layer: a second block)
+        const float bb = p.b1[nb * 16 + r16];
+        const ff32x4 acc = wmma(sF, LD, wv1, nv1, lane);
+        if constexpr (ALL2) {   // the second GEMM's weights, all of this wave's blocks, go out behind the last MFMA of the first
+#pragma unroll
+            for (int v2 = 0; v2 < NB2; ++v2)
+                if (wave + FF_WAVES * v2 < nblk2) wload(w2all[v2], p.w2 + (size_t)(wave + FF_WAVES * v2) * 16 * p.ldw2, p.ldw2, NV2, lane);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sH[(4 * g4 + e) * LH + nb * 16 + r16] = gelu_erf(acc[e] + bb);
     }
-    __syncthreads();
+    FF_BARRIER();
+    if (p.dbg) stamp[2] = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 2: f2 = h W2^T + b2 + n1 (into sF; columns past d: zero weights, zero bias, zero n1)
-    for (int nb = wave; nb < p.ld / 16; nb += FF_WAVES) {
-        const ff32x4 acc = mfma_block_16(sH, LH, p.w2 + (size_t)nb * 16 * p.ldw2, p.ldw2, p.hid, lane);
-        const int col = nb * 16 + r16;
+    auto finish2 = [&](int nbx, const ff32x4 &acc) {
+        const int col = nbx * 16 + r16;
         const float bb = p.b2[col];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int lr = 4 * g4 + e;
             sF[lr * LD + col] = acc[e] + bb + sN[lr * LD + col];
         }
+    };
+    if constexpr (ALL2) {
+#pragma unroll
+        for (int v2 = 0; v2 < NB2; ++v2) {
+            const int nbx = wave + FF_WAVES * v2;
+            if (nbx < nblk2) finish2(nbx, wmma(sH, LH, w2all[v2], NV2, lane));
+        }
+    } else {
+        // this wave's column blocks two at a time: both blocks' weights are requested before either is multiplied
+        for (int nb = wave; nb < nblk2; nb += 2 * FF_WAVES) {
+            ff32x4 wa[NV2], wb[NV2];
+            const int nb2 = nb + FF_WAVES;
+            wload(wa, p.w2 + (size_t)nb * 16 * p.ldw2, p.ldw2, NV2, lane);
+            if (nb2 < nblk2) wload(wb, p.w2 + (size_t)nb2 * 16 * p.ldw2, p.ldw2, NV2, lane);
+            finish2(nb, wmma(sH, LH, wa, NV2, lane));
+            if (nb2 < nblk2) finish2(nb2, wmma(sH, LH, wb, NV2, lane));
+        }
     }
-    __syncthreads();
+    FF_BARRIER();
+    if (p.dbg) stamp[3] = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 3: LayerNorm2 (or none) and the output rows, pad columns written as zeros
+    {
+        ff32x4 v[2][FF_VEC];
 #pragma unroll
-    for (int rr = 0; rr < FF_ROWS / FF_WAVES; ++rr) {
-        const int lr = wave * (FF_ROWS / FF_WAVES) + rr, row = row0 + lr;
-        if (row >= p.rows) continue;
-        float v[FF_MAX_PER_LANE];
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int i = 0; i < FF_MAX_PER_LANE; ++i) {
-            const int c = lane + 64 * i;
-            v[i] = c < p.d ? sF[lr * LD + c] : 0.f;
+            for (int i = 0; i < FF_VEC; ++i) {
+                const int c = 4 * lane + 256 * i;
+                v[r][i] = ff32x4{0.f, 0.f, 0.f, 0.f};
+                if (c < p.ld) v[r][i] = *reinterpret_cast<const ff32x4 *>(&sF[(2 * wave + r) * LD + c]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[r][i][e] = (c + e) < p.d ? v[r][i][e] : 0.f;
+            }
+        if (p.n2g) ln_rows2(v, p.d, lane, sP + 4 * p.ld, sP + 5 * p.ld);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = row0 + 2 * wave + r;
+#pragma unroll
+            for (int i = 0; i < FF_VEC; ++i) {
+                const int c = 4 * lane + 256 * i;
+                if (row < p.rows && c < p.ldo) *reinterpret_cast<ff32x4 *>(p.out + (size_t)row * p.ldo + c) = v[r][i];
+            }
         }
-        if (p.n2g) ln_row(v, p.d, lane, p.n2g, p.n2b);
-#pragma unroll
-        for (int i = 0; i < FF_MAX_PER_LANE; ++i) {
-            const int c = lane + 64 * i;
-            if (c < p.ldo) p.out[(size_t)row * p.ldo + c] = v[i];
-        }
+    }
+    if (p.dbg) {
+        stamp[4] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) for (int i = 0; i < 5; ++i) p.dbg[(size_t)blockIdx.x * 8 + i] = stamp[i];
     }
 }
 
 hipError_t launch_ff_block(const FfBlockParams &p, hipStream_t s) {
     if (p.rows <= 0) return hipSuccess;
-    if (p.d > 64 * FF_MAX_PER_LANE || p.ld > 64 * FF_MAX_PER_LANE || p.ldo > 64 * FF_MAX_PER_LANE || p.ld % 16 || p.ld < p.d ||
-        (p.hid != 128 && p.hid != 256) || p.ldw1 < p.ld || p.ldw2 < p.hid || (p.ldw1 & 3) || (p.ldw2 & 3) || (!p.slab && !p.x) ||
-        (p.slab && (p.S < 1 || !p.bias0)))
+    if (p.d > 256 * FF_VEC || p.ld > 256 * FF_VEC || p.ldo != p.ld || p.ld % 16 || p.ld < p.d || (p.lds & 3) || (p.ldr & 3) || (p.ldx & 3) ||
+        p.ld > 16 * FF_NV1 || (p.hid != 128 && p.hid != 256) || p.ldw1 < p.ld || p.ldw2 < p.hid || (p.ldw1 & 3) || (p.ldw2 & 3) || (!p.slab && !p.x) ||
+        (p.slab && (p.S < 1 || p.S > 4 || !p.bias0)))
         return hipErrorInvalidValue;
-    const size_t lds = ((size_t)2 * FF_ROWS * (p.ld + 4) + (size_t)FF_ROWS * (p.hid + 4)) * sizeof(float);
+    const size_t lds = ((size_t)2 * FF_ROWS * (p.ld + 4) + (size_t)FF_ROWS * (p.hid + 4) + (size_t)6 * p.ld) * sizeof(float);
     static bool configured[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ff_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ff_block_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ff_block_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         configured[dev] = true;
     }
-    hipLaunchKernelGGL(ff_block_kernel, dim3((p.rows + FF_ROWS - 1) / FF_ROWS), dim3(64 * FF_WAVES), lds, s, p);
+    const dim3 grid((p.rows + FF_ROWS - 1) / FF_ROWS), block(64 * FF_WAVES);
+    if (p.hid == 128) hipLaunchKernelGGL(ff_block_kernel<128>, grid, block, lds, s, p);
+    else hipLaunchKernelGGL(ff_block_kernel<256>, grid, block, lds, s, p);
     return hipGetLastError();
 }
 
@@ -224,21 +325,35 @@ __global__ __launch_bounds__(384) void cheb_layer1_kernel(const float *__restric
     float *sT = sY + 3 * 32 * 16;    // [3][21][21]
     const int b = blockIdx.x, o0 = blockIdx.y * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rb = wave & 1, kord = wave >> 1;   // row block, Chebyshev order of this wave's 16 x 16 MFMA block
+    ff32x4 wv[FF_NV1];
+    wload(wv, w + (size_t)(kord * co + o0) * ldw, ldw, K >> 4, lane);   // in flight while the token rows are staged
     for (int i = tid; i < 3 * 21 * 21; i += 384) sT[i] = tk[i];
     const int k4 = K >> 2;
-    for (int i = tid; i < 32 * k4; i += 384) {
-        const int r = i / k4, c = i - r * k4;
-        ff32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < 21) v = *reinterpret_cast<const ff32x4 *>(x + ((size_t)b * 21 + r) * ldx + 4 * c);
-        *reinterpret_cast<ff32x4 *>(sX + r * LD + 4 * c) = v;
+    {   // the sample's 21 token rows: every load is issued before the first store (K <= 576: at most 8 vectors per thread)
+        ff32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 384 * u, r = i / k4, c = i - r * k4;
+            v[u] = ff32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < 21 * k4) v[u] = *reinterpret_cast<const ff32x4 *>(x + ((size_t)b * 21 + r) * ldx + 4 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 384 * u, r = i / k4, c = i - r * k4;
+            if (i < 21 * k4) *reinterpret_cast<ff32x4 *>(sX + r * LD + 4 * c) = v[u];
+        }
+        for (int i = 21 * k4 + tid; i < 32 * k4; i += 384) {   // padding rows 21 .. 31
+            const int r = i / k4, c = i - r * k4;
+            *reinterpret_cast<ff32x4 *>(sX + r * LD + 4 * c) = ff32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     __syncthreads();
     {
-        const int rb = wave & 1, k = wave >> 1;   // row block, Chebyshev order
-        const ff32x4 acc = mfma_block_16(sX + rb * 16 * LD, LD, w + (size_t)(k * co + o0) * ldw, ldw, K, lane);
+        const ff32x4 acc = wmma(sX + rb * 16 * LD, LD, wv, K >> 4, lane);
         const int r16 = lane & 15, g4 = lane >> 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sY[(k * 32 + rb * 16 + 4 * g4 + e) * 16 + r16] = acc[e];
+        for (int e = 0; e < 4; ++e) sY[(kord * 32 + rb * 16 + 4 * g4 + e) * 16 + r16] = acc[e];
     }
     __syncthreads();
     if (tid < 21 * 16) {
@@ -274,23 +389,46 @@ __global__ __launch_bounds__(512) void cheb_tail_kernel(const float *__restrict_
     float *sT = sZ + 32 * LD2;        // [3][21][21]
     float *sY3 = sT + 3 * 21 * 21;    // [32][16]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // every weight vector this wave will need is requested before anything else: blocks t = wave, wave + 8, wave + 16 of layer 2
+    // (row block t & 1, column block t >> 1; c1 <= 256) and layer 3's single column block (c2 <= 64)
+    const int nblk = 2 * (3 * c2 / 16);
+    ff32x4 w2v[3][16], w3v[4];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+        if (wave + 8 * u < nblk) wload(w2v[u], w2 + (size_t)((wave + 8 * u) >> 1) * 16 * ldw2, ldw2, c1 >> 4, lane);
+    if (wave < 2) wload(w3v, w3, ldw3, c2 >> 4, lane);
     for (int i = tid; i < 3 * 21 * 21; i += 512) sT[i] = tk[i];
     const int k4 = c1 >> 2;
-    for (int i = tid; i < 32 * k4; i += 512) {
-        const int r = i / k4, c = i - r * k4;
-        ff32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < 21) v = *reinterpret_cast<const ff32x4 *>(x + ((size_t)b * 21 + r) * ldx + 4 * c);
-        *reinterpret_cast<ff32x4 *>(sX + r * LD1 + 4 * c) = v;
+    {   // layer-1 output rows of the sample (c1 <= 256: at most 3 vectors per thread), loads before stores
+        ff32x4 v[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = tid + 512 * u, r = i / k4, c = i - r * k4;
+            v[u] = ff32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < 21 * k4) v[u] = *reinterpret_cast<const ff32x4 *>(x + ((size_t)b * 21 + r) * ldx + 4 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = tid + 512 * u, r = i / k4, c = i - r * k4;
+            if (i < 21 * k4) *reinterpret_cast<ff32x4 *>(sX + r * LD1 + 4 * c) = v[u];
+        }
+        for (int i = 21 * k4 + tid; i < 32 * k4; i += 512) {
+            const int r = i / k4, c = i - r * k4;
+            *reinterpret_cast<ff32x4 *>(sX + r * LD1 + 4 * c) = ff32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     for (int i = tid; i < 32 * LD2; i += 512) sZ[i] = 0.f;
     __syncthreads();
     const int r16 = lane & 15, g4 = lane >> 4;
-    const int nblk = 2 * (3 * c2 / 16);
-    for (int t = wave; t < nblk; t += 8) {
-        const int rb = t & 1, nb = t >> 1;
-        const ff32x4 acc = mfma_block_16(sX + rb * 16 * LD1, LD1, w2 + (size_t)nb * 16 * ldw2, ldw2, c1, lane);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sY[(rb * 16 + 4 * g4 + e) * LY + nb * 16 + r16] = acc[e];
+    for (int u = 0; u < 3; ++u) {
+        const int t = wave + 8 * u;
+        if (t < nblk) {
+            const int rb = t & 1, nb = t >> 1;
+            const ff32x4 acc = wmma(sX + rb * 16 * LD1, LD1, w2v[u], c1 >> 4, lane);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sY[(rb * 16 + 4 * g4 + e) * LY + nb * 16 + r16] = acc[e];
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < 21 * c2; idx += 512) {
@@ -308,7 +446,7 @@ __global__ __launch_bounds__(512) void cheb_tail_kernel(const float *__restrict_
     }
     __syncthreads();
     if (wave < 2) {   // layer 3: 3 * c3 <= 16 columns (the packed weights are zero-padded to 16 rows and beyond)
-        const ff32x4 acc = mfma_block_16(sZ + wave * 16 * LD2, LD2, w3, ldw3, c2, lane);
+        const ff32x4 acc = wmma(sZ + wave * 16 * LD2, LD2, w3v, c2 >> 4, lane);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sY3[(wave * 16 + 4 * g4 + e) * 16 + r16] = acc[e];
     }
@@ -329,7 +467,7 @@ __global__ __launch_bounds__(512) void cheb_tail_kernel(const float *__restrict_
 
 hipError_t launch_cheb_fused(const ChebFusedParams &p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
-    if (p.K % 16 || p.ldx < p.K || p.ldw1 < p.K || p.c1 % 16 || (3 * p.c2) % 16 || p.c2 % 16 || 3 * p.c3 > 16 || p.ldw2 < p.c1 || p.ldw3 < p.c2 ||
+    if (p.K > 16 * FF_NV1 || p.c1 > 256 || p.c2 > 64 || 2 * (3 * p.c2 / 16) > 24 || p.K % 16 || p.ldx < p.K || p.ldw1 < p.K || p.c1 % 16 || (3 * p.c2) % 16 || p.c2 % 16 || 3 * p.c3 > 16 || p.ldw2 < p.c1 || p.ldw3 < p.c2 ||
         (p.ldx & 3) || (p.ldw1 & 3) || (p.ldw2 & 3) || (p.ldw3 & 3) || !p.scratch)
         return hipErrorInvalidValue;
     const size_t lds1 = ((size_t)32 * (p.K + CH_LDX_PAD) + 3 * 32 * 16 + 3 * 21 * 21) * sizeof(float);

@@ -163,6 +163,7 @@ struct FfBlockParams {
     const float *n2g, *n2b;
     float *out; int ldo;
     int hid;                               // 128 | 256
+    unsigned long long *dbg;               // diagnostic builds only: 100 MHz stamps at the phase boundaries of workgroup 0
 };
 hipError_t launch_ff_block(const FfBlockParams &p, hipStream_t s);
 // JointsDecoderGCN (nets.py:133-139): three ChebConv layers K -> c1 -> c2 -> c3 in two launches (layer 1 per (sample, 16

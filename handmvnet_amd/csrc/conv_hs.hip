@@ -1,0 +1,300 @@
+// conv_hs.hip -- persistent, weight-stationary R x S convolution for few-channel layers of the fp16 path ("halo stream").
+//
+// Replaces, for large pixel counts, the stride-1 convolutions whose whole weight tensor fits one workgroup's registers:
+//   * the 3x3 conv2 of layer1's Bottlenecks, 64 -> 64 channels at H/4 (/root/reference/src/models/backbones/resnet.py:114-118,
+//     132-134) -- and with them every 64-channel 3x3 of the BasicBlock ResNets (resnet.py:77-106) on the fp16 path;
+//   * the stem conv1 7x7 s2 (resnet.py:218), which the engine runs as a 4x4 stride-1 convolution over 2x2 space-to-depth
+//     frames of 16 channels.
+// conv_igemm gives these layers 128 x 64 tiles: per tile it re-reads the shifted pixel tile once per tap (9 x 16 KB) and
+// re-streams the weights (72 KB) for 16 KB of input and 16 KB of output -- 0.24 of the HBM roofline on algorithmic bytes.
+//
+// MI355X mapping (conv_stream.hip's structure with a halo image in place of a GEMM row tile)
+//   * ONE workgroup per CU for the whole launch, walking 16 x 16 output blocks; the WEIGHTS LIVE IN REGISTERS (a wave keeps
+//     the MFMA A-operand fragments of its 32 * TN output channels for all R * S taps: 144 VGPRs for 3x3 x 64 channels);
+//   * per block the (16 + R - 1) x (16 + S - 1) halo of input pixels arrives ONCE by LDS-DMA (41 KB for 3x3 x 64 channels,
+//     XOR-swizzled on the source side) into a ring of NSLOT images; the R * S taps read it at shifted rows, so a pixel is
+//     fetched 1.27x (halo) instead of 9x;
+//   * one static schedule per block, identical for every wave: wait(halo landed) . barrier . DMA halo of block t + D .
+//     [DMA residual of block t + 1] . R * S * CPT k16 MFMA steps . wait(residual) . epilogue; every wait is a counted
+//     `s_waitcnt vmcnt(N)` (sched_* in conv_stream.hip's sense); blocks past the stream's end use the zero / trash pages;
+//   * operand roles, K order (tap-major, channels inside), bias-as-initial-accumulator and the epilogue arithmetic are
+//     conv_igemm's, so the results are BIT-IDENTICAL to conv_igemm's (tests/test_gpu_parity.py::test_stream_kernel_is_bit_identical).
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "kernels.h"
+
+namespace hmv {
+
+typedef float hf32x16 __attribute__((ext_vector_type(16)));
+typedef float hf32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 hf16x8 __attribute__((ext_vector_type(8)));
+
+#define HMV_HGLDS16(gptr, lptr)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+template <int N>
+__device__ __forceinline__ void hs_wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// A block's vector-memory instructions, in issue order: HP halo DMAs (block t + D), RB residual DMAs (block t + 1), OS stores.
+// "X landed" == "at most the instructions issued after X are still out".
+constexpr int hs_after_halo(int D, int HP, int RB, int OS) { return RB + OS + (D - 1) * (HP + RB + OS); }   // waited at the top of block t
+constexpr int hs_after_residual(int HP, int RB, int OS) { return OS + HP + RB; }                              // waited before the epilogue of t
+
+// R x S taps, CPT k16 steps (16 input channels each) per tap; wave grid MW x NW over (pixel blocks x channel blocks);
+// TM 32-pixel blocks (= two rows of the 16 x 16 output block) and TN 32-channel blocks per wave; MW * TM == 8.
+template <int R, int S, int CPT, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES>
+__global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
+    constexpr int NWV = MW * NW;
+    constexpr int HH = 16 + R - 1, HW = 16 + S - 1, HROWS = HH * HW;
+    constexpr int LPR = CPT * 2;                       // 16-byte chunks per halo pixel
+    constexpr int RPP = 512 / LPR;                     // halo pixels filled per DMA pass
+    constexpr int HP = (HROWS + RPP - 1) / RPP;        // DMA instructions per halo image and thread
+    constexpr int SLOT = HP * RPP * LPR * 16;          // bytes of one halo image (padded to whole passes)
+    constexpr int D = NSLOT - 1;
+    constexpr int RB = HAS_RES ? TM * TN * 2 : 0, OS = TM * TN * 2;
+    constexpr int ZW = TM * TN * 2 * 1024;
+    constexpr int NSTEP = R * S * CPT;
+    static_assert(NWV == 8 && MW * TM == 8 && (LPR == 8 || LPR == 2), "eight waves over eight 32-pixel blocks; 64- or 16-channel pixels");
+    extern __shared__ __attribute__((aligned(16))) char hsm[];
+    char *zones = hsm + NSLOT * SLOT;                  // [2][NWV][ZW]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int mw = wave / NW, nw = wave - mw * NW;
+    const int n0 = nw * TN * 32;                       // this wave's first output channel
+
+    // ---- the blocks of this workgroup: b = blockIdx.x, + gridDim.x, ...
+    const int tyn = p.Ho >> 4, txn = p.Wo >> 4, per_img = tyn * txn, nblk = p.N * per_img;
+    const int ntl = nblk > (int)blockIdx.x ? (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    if (ntl == 0) return;
+
+    const _Float16 *zero16 = reinterpret_cast<const _Float16 *>(p.zero);
+    _Float16 *trash = reinterpret_cast<_Float16 *>(const_cast<float *>(p.zero) + 64 + 4 * lane);
+    const _Float16 *Ain = reinterpret_cast<const _Float16 *>(p.in);
+    const _Float16 *Rin = reinterpret_cast<const _Float16 *>(p.res);
+    _Float16 *Out = reinterpret_cast<_Float16 *>(p.out);
+
+    // ---- weights -> registers, once: block b, step Q (tap Q / CPT, channels 16 (Q % CPT) ..): 8 halfs k = 16 Q + 8 kh .. of row
+    // swap23(l31) (conv_igemm's transposed-output convention: registers 8j .. 8j+7 are eight consecutive channels)
+    const int wl31 = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    hf16x8 wreg[TN][NSTEP];
+    {
+        const _Float16 *wb = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(n0 + wl31) * p.ldw + 8 * kh;
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int Q = 0; Q < NSTEP; ++Q) wreg[b][Q] = *reinterpret_cast<const hf16x8 *>(wb + (size_t)(32 * b) * p.ldw + 16 * Q);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- halo DMA roles, block-invariant: pass i fills halo pixel hp = i * RPP + tid / LPR, chunk tid % LPR (the chunk it
+    // FETCHES is XOR-swizzled so that the lane-linear LDS image is conflict-free for the fragment reads)
+    const int hchunk = tid % LPR;
+    int hyx[HP];   // (row << 8 | column) of the halo pixel; rows past the halo get row 200: always out of the image -> zero page
+#pragma unroll
+    for (int i = 0; i < HP; ++i) {
+        const int hp = i * RPP + tid / LPR;
+        hyx[i] = ((hp < HROWS ? hp / HW : 200) << 8) | (hp - (hp / HW) * HW);
+    }
+    const int kqs = LPR == 8 ? (hchunk ^ ((tid >> 4) & 7)) : hchunk;   // (pixel >> 1) & 7 == (tid >> 4) & 7: RPP = 64 is a multiple of 16
+
+    auto block_origin = [&](int tt, int &n, int &by, int &bx) {
+        const int g = (int)blockIdx.x + tt * (int)gridDim.x;
+        n = g / per_img;
+        const int rem = g - n * per_img;
+        by = rem / txn;
+        bx = rem - by * txn;
+    };
+    auto issue_halo = [&](int tt) {
+        int n, by, bx;
+        block_origin(tt, n, by, bx);
+        const bool live = tt >= 0 && tt < ntl;
+        char *dst = hsm + (((tt % NSLOT) + NSLOT) % NSLOT) * SLOT + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < HP; ++i) {
+            const int iy = by * 16 - p.pad_h + (hyx[i] >> 8), ix = bx * 16 - p.pad_w + (hyx[i] & 255);
+            const bool ok = live && (hyx[i] >> 8) < 200 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const _Float16 *src = ok ? Ain + ((size_t)(n * p.H + iy) * p.W + ix) * p.lda + 8 * kqs : zero16;
+            asm volatile("" : "+v"(src));   // ONE DMA instruction per schedule entry
+            HMV_HGLDS16(src, dst + i * 8192);
+        }
+    };
+    // pixel of lane l31 in 32-pixel block a of this wave: output row 2 (mw TM + a) + (l31 >> 4), column l31 & 15
+    auto issue_R = [&](int tt) {
+        if constexpr (HAS_RES) {
+            int n, by, bx;
+            block_origin(tt, n, by, bx);
+            const bool live = tt >= 0 && tt < ntl;
+            char *z = zones + ((tt & 1) * NWV + wave) * ZW;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const size_t pix = (size_t)(n * p.Ho + by * 16 + 2 * (mw * TM + a) + (l31 >> 4)) * p.Wo + bx * 16 + (l31 & 15);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const _Float16 *src = live ? Rin + pix * p.ldr + n0 + 32 * b + 16 * j + 8 * kh : zero16;
+                        asm volatile("" : "+v"(src));
+                        HMV_HGLDS16(src, z + ((a * TN + b) * 2 + j) * 1024);
+                    }
+            }
+        }
+    };
+
+    // ---- prologue: the D blocks "before the first" replay the schedule (real DMAs where they belong to block 0 .., dummies else)
+    for (int ft = -D; ft < 0; ++ft) {
+        issue_halo(ft + D);
+        issue_R(ft + 1);
+#pragma unroll
+        for (int i = 0; i < OS; ++i)
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(trash), "v"(hf32x4{0.f, 0.f, 0.f, 0.f}) : "memory");
+    }
+
+    const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    const __attribute__((address_space(4))) float *bp0 =
+        (const __attribute__((address_space(4))) float *)(p.bias + __builtin_amdgcn_readfirstlane(n0));
+    // halo pixel index of the lane's output pixel at tap (0, 0), per block a
+    int hb[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) hb[a] = (2 * (mw * TM + a) + (l31 >> 4)) * HW + (l31 & 15);
+    hf32x16 acc[TM][TN];
+
+    for (int tt = 0; tt < ntl; ++tt) {
+        int bz;   // bias re-read per block behind an opaque zero offset (scalar cache): hoisted it would cost 16 TN VGPRs
+        asm volatile("s_mov_b32 %0, 0" : "=s"(bz));
+        const __attribute__((address_space(4))) float *bp = bp0 + bz;
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = 32 * b + 16 * (e >> 3) + (e & 7);
+                const float v0 = bp[c], v1 = bp[c + 8];
+                const float v = kh ? v1 : v0;
+#pragma unroll
+                for (int a = 0; a < TM; ++a) acc[a][b][e] = v;
+            }
+        hs_wait_vm<hs_after_halo(D, HP, RB, OS)>();                           // my share of halo(tt) has landed
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // everyone's has; everyone is done with halo(tt - 1)
+        issue_halo(tt + D);                                                   // ... whose slot takes halo(tt + D)
+        issue_R(tt + 1);
+        const char *himg = hsm + (tt % NSLOT) * SLOT;
+        // the fragment addresses are block-invariant: left visible, the compiler hoists all R * S * CPT * TM of them out of the
+        // block loop and spills them (the weights hold 144 registers).  An opaque zero makes them this block's own arithmetic.
+        int hz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(hz));
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    hf16x8 px[TM];
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const int h = hb[a] + hz + r * HW + s;
+                        const int ch = LPR == 8 ? ((2 * j + kh) ^ ((h >> 1) & 7)) : kh;
+                        px[a] = *reinterpret_cast<const hf16x8 *>(himg + (h * LPR + ch) * 16);
+                    }
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[b][(r * S + s) * CPT + j], px[a], acc[a][b], 0, 0, 0);
+                    // keep the scheduler from hoisting every tap's address arithmetic and fragment reads to the top of the block
+                    // (the weights already hold 144 registers: that hoisting spilled 40)
+                    if (j == CPT - 1) __builtin_amdgcn_sched_barrier(0);
+                }
+        // ---- epilogue
+        if constexpr (HAS_RES) hs_wait_vm<hs_after_residual(HP, RB, OS)>();
+        int n, by, bx;
+        block_origin(tt, n, by, bx);
+        const char *z = zones + ((tt & 1) * NWV + wave) * ZW + lane * 16;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const size_t pix = (size_t)(n * p.Ho + by * 16 + 2 * (mw * TM + a) + (l31 >> 4)) * p.Wo + bx * 16 + (l31 & 15);
+            _Float16 *orow = Out + pix * p.ldc + n0 + 8 * kh;
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    hf16x8 rr = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if constexpr (HAS_RES) rr = *reinterpret_cast<const hf16x8 *>(z + ((a * TN + b) * 2 + j) * 1024);
+                    hf16x8 hv;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + (float)rr[u], lo);
+                    _Float16 *dst = orow + 32 * b + 16 * j;   // (every block of a launch is whole: H and W are multiples of 16)
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(hv) : "memory");
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// ====================================================================== host side
+static int g_hs_mode = -1;   // -1: the launcher's rule (HMV_NO_HS=1 disables it); 0 never; 1 whenever supported (op-level tests)
+void conv_hs_set_mode(int mode) { g_hs_mode = mode; }
+
+// 0: no instantiation; 1: 3x3 pad 1, 64 -> 64 channels; 2: the 4x4 space-to-depth stem, 16 -> 64 channels
+static int hs_kind(const ConvParams &p) {
+    if (p.R == 3 && p.S == 3 && p.pad_h == 1 && p.pad_w == 1 && p.Cin == 64 && p.Cout == 64 && p.Kpad == 576) return 1;
+    if (p.R == 4 && p.S == 4 && p.pad_h == 2 && p.pad_w == 2 && p.Cin == 16 && p.Cout == 64 && p.Kpad == 256 && !p.res) return 2;
+    return 0;
+}
+
+bool conv_hs_supported(const ConvParams &p) {
+    static int off = -1;   // development knob: HMV_NO_HS=1 keeps these convs on conv_igemm (A/B runs)
+    if (off < 0) off = getenv("HMV_NO_HS") ? 1 : 0;
+    if (g_hs_mode == 0 || (g_hs_mode < 0 && off)) return false;
+    if (!hs_kind(p) || !p.in_f16 || !p.out_f16 || (p.res && !p.res_f16)) return false;
+    if (p.stride != 1 || p.up || p.in2 || p.ksl > 1 || p.phases > 1 || p.Ho != p.H || p.Wo != p.W || (p.H & 15) || (p.W & 15)) return false;
+    if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out || p.fill) return false;
+    if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
+    if ((p.lda ? p.lda : p.Cin) != p.Cin || ((p.ldw ? p.ldw : p.Kpad) & 7) || (p.ldc & 7) || (p.res && (p.ldr & 7))) return false;
+    if (g_hs_mode > 0) return true;
+    return (long long)p.N * (p.H >> 4) * (p.W >> 4) >= 4 * 256;   // at least four blocks per workgroup
+}
+
+template <int R, int S, int CPT, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES>
+static hipError_t launch_hs_one(const ConvParams &p, hipStream_t s) {
+    constexpr int HROWS = (16 + R - 1) * (16 + S - 1), LPR = CPT * 2, RPP = 512 / LPR, HP = (HROWS + RPP - 1) / RPP;
+    constexpr size_t lds = (size_t)NSLOT * HP * RPP * LPR * 16 + (HAS_RES ? (size_t)2 * 8 * TM * TN * 2 * 1024 : 0);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool configured[64] = {};
+    auto kern = conv_hs_f16<R, S, CPT, TM, TN, MW, NW, NSLOT, HAS_RES>;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!configured[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[dev] = true;
+    }
+    const int nblk = p.N * (p.H >> 4) * (p.W >> 4);
+    hipLaunchKernelGGL(kern, dim3(nblk < 256 ? nblk : 256), dim3(512), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name) {
+    switch (hs_kind(p)) {
+        case 1:
+            if (p.res) {
+                if (name) *name = "conv_hs_f16<3x3,64->64,res>";
+                return launch_hs_one<3, 3, 4, 2, 1, 4, 2, 2, true>(p, s);
+            }
+            if (name) *name = "conv_hs_f16<3x3,64->64>";
+            return launch_hs_one<3, 3, 4, 2, 1, 4, 2, 3, false>(p, s);   // no landing zones: three halo images (two in flight)
+        case 2:
+            if (name) *name = "conv_hs_f16<4x4,16->64>";
+            return launch_hs_one<4, 4, 1, 2, 1, 4, 2, 4, false>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace hmv

@@ -1331,6 +1331,8 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     if (!generic && conv_stream_supported(p)) return launch_conv_stream(p, s, name);
     // MFMA-heavy fp16 1x1 convs without a residual on 256 x 256 tiles: the counted-vmcnt, phase-interleaved main loop
     if (!generic && conv_gemm8_supported(p)) return launch_conv_gemm8(p, s, name);
+    // few-channel fp16 layers (3x3 64 -> 64, the space-to-depth stem) over many pixels: weights in registers, halo images streamed
+    if (!generic && conv_hs_supported(p)) return launch_conv_hs(p, s, name);
     if (p.ksl > 1 && (!one || p.in_f16 || p.in2 || p.up || p.res || p.act != ACT_NONE || p.kslice <= 0 || p.kslice % 32 != 0 ||
                       p.ksl * p.kslice != p.Kpad || p.Cin % 32 != 0))
         return hipErrorInvalidValue;   // split-K: plain fp32 GEMM slices, epilogue left to the reduction kernel

@@ -2108,9 +2108,11 @@ extern "C" int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int
     if (kernel_sel < 0 || kernel_sel > 2) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0, 1 or 2"; return HMV_ERR_ARG; }
     conv_stream_set_mode(kernel_sel == 0 ? -1 : kernel_sel - 1);
     conv_gemm8_set_mode(kernel_sel == 0 ? -1 : kernel_sel - 1);
+    conv_hs_set_mode(kernel_sel == 0 ? -1 : kernel_sel - 1);
     const int rc = op_conv2d_any("hmv_op_conv2d_f16", device, HMV_F16, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad,
                                  residual, relu, out_f16, true, kernel_name, stream);
     conv_stream_set_mode(-1);
     conv_gemm8_set_mode(-1);
+    conv_hs_set_mode(-1);
     return rc;
 }

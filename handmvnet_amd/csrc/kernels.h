@@ -149,6 +149,12 @@ bool conv_gemm8_supported(const ConvParams &p);
 void conv_gemm8_set_mode(int mode);   // -1 launcher's rule, 0 never, 1 whenever supported (op-level tests)
 hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name);
 
+// conv_hs.hip: persistent weight-stationary R x S convolution for few-channel fp16 layers (3x3 64 -> 64; the 4x4 space-to-depth
+// stem): weights in registers, one halo image per 16 x 16 output block.  Bit-identical to conv_igemm's result.
+bool conv_hs_supported(const ConvParams &p);
+void conv_hs_set_mode(int mode);
+hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name);
+
 // ---- fusion_kernels.hip: the launch-bound tail as fused kernels
 // Everything of a fusion block behind its to_out GEMM (layers.py:224-233 / 161-174; learnable-query blocks: layers.py:293-299):
 //   t = (slab: sum of S split-K slices + bias0 + residual row | x row);  n1 = n1g ? LN(t) : t;  f0 = LN_ff(n1);

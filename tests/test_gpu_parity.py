@@ -267,6 +267,12 @@ GEMM8_SHAPES = [(4, 32, 32, 1024, 256, 1, 1, 0, False, True), (3, 17, 19, 512, 5
                 (8, 32, 32, 1024, 512, 1, 1, 0, False, True)]
 
 
+# 3x3 64 -> 64 convs on the halo-streaming weight-stationary kernel (conv_hs.hip): images of 1 x 1 to 4 x 4 blocks of 16 x 16 pixels,
+# non-square, more blocks than workgroups' first round and fewer, with and without a residual / ReLU
+HS_SHAPES = [(4, 32, 32, 64, 64, 3, 1, 1, False, True), (3, 48, 16, 64, 64, 3, 1, 1, True, True), (1, 16, 16, 64, 64, 3, 1, 1, False, False),
+             (40, 64, 64, 64, 64, 3, 1, 1, False, True), (24, 64, 32, 64, 64, 3, 1, 1, True, False)]
+
+
 def _run_conv_f16(shape, sel):
     from handmvnet_amd import _lib
     lib = _lib.load()
@@ -289,19 +295,20 @@ def _run_conv_f16(shape, sel):
     return out.cpu(), kname.value.decode(), (x, w, b, res, relu)
 
 
-@pytest.mark.parametrize("shape", STREAM_SHAPES + GEMM8_SHAPES)
+@pytest.mark.parametrize("shape", STREAM_SHAPES + GEMM8_SHAPES + HS_SHAPES)
 def test_stream_kernel_is_bit_identical(shape):
     """The persistent weight-stationary kernel against conv_igemm on the same operands: same bits (it keeps conv_igemm's operand
     roles, accumulation order and epilogue arithmetic -- which is what makes a sample's result independent of the batch whichever
     kernel the launcher picks), and both against torch fp64 at fp16 accuracy."""
     a, ka, (x, w, b, res, relu) = _run_conv_f16(shape, 2)
     c, kc, _ = _run_conv_f16(shape, 1)
-    assert ka.startswith("conv_stream_f16" if shape[8] else "conv_gemm8_f16") and kc.startswith("conv_igemm_f16"), (ka, kc)
+    want = "conv_hs_f16" if shape[5] == 3 else ("conv_stream_f16" if shape[8] else "conv_gemm8_f16")
+    assert ka.startswith(want) and kc.startswith("conv_igemm_f16"), (ka, kc)
     assert torch.isfinite(a.float()).all()
     assert torch.equal(a.view(torch.int16), c.view(torch.int16)), (ka, kc, (a.float() - c.float()).abs().max())
     if shape[0] * shape[1] * shape[2] <= 8192:   # fp64 reference on the CPU for the small cases
         xh, wh = x.half().double(), w.half().double()
-        ref = torch.einsum("nhwc,oc->nhwo", xh, wh[:, :, 0, 0]) + b.double()
+        ref = torch.nn.functional.conv2d(xh.permute(0, 3, 1, 2), wh, b.double(), stride=shape[6], padding=shape[7]).permute(0, 2, 3, 1)
         if res is not None:
             ref = ref + res.half().double()
         if relu:

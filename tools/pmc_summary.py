@@ -37,6 +37,14 @@ def family(name: str) -> str:
         k16 = ",k16" if m.group(4) == "32" else ""
         return f"conv_igemm_f16<{m.group(1)}x{m.group(2)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense", "3": "halo"}[m.group(3)] + \
             (",rowsum" if m.group(5) == "1" else "") + ">"
+    # round 3: conv_stream_f16<TM, TN, MW, NW, NP, NSLOT, HAS_RES, SPREAD, NT> and conv_gemm8_f16<DUAL>
+    m = re.match(r"(?:void )?(?:hmv::)?conv_stream_f16<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, (true|false)", name)
+    if m:
+        tm, tn, mw, nw, np_ = (int(m.group(i)) for i in range(1, 6))
+        return f"conv_stream_f16<{32 * tm * mw}x{32 * tn * nw},k{64 * np_}" + (",res>" if m.group(6) == "true" else ">")
+    m = re.match(r"(?:void )?(?:hmv::)?conv_gemm8_f16<(true|false)>", name)
+    if m:
+        return "conv_gemm8_f16<256x256,1x1" + (",dual>" if m.group(1) == "true" else ">")
     return re.sub(r"\(.*", "", name).replace("void ", "").replace("hmv::", "")
 
 

@@ -15,7 +15,7 @@
 //     XOR-swizzled on the source side) into a ring of NSLOT images; the R * S taps read it at shifted rows, so a pixel is
 //     fetched 1.27x (halo) instead of 9x;
 //   * one static schedule per block, identical for every wave: wait(halo landed) . barrier . DMA halo of block t + D .
-//     [DMA residual of block t + 1] . R * S * CPT k16 MFMA steps . wait(residual) . epilogue; every wait is a counted
+//     [DMA residual of block t + 1] . ceil(R * S * CPP / 2) k16 MFMA steps . wait(residual) . epilogue; every wait is a counted
 //     `s_waitcnt vmcnt(N)` (sched_* in conv_stream.hip's sense); blocks past the stream's end use the zero / trash pages;
 //   * operand roles, K order (tap-major, channels inside), bias-as-initial-accumulator and the epilogue arithmetic are
 //     conv_igemm's, so the results are BIT-IDENTICAL to conv_igemm's (tests/test_gpu_parity.py::test_stream_kernel_is_bit_identical).
@@ -47,21 +47,23 @@ __device__ __forceinline__ void hs_wait_vm() {
 constexpr int hs_after_halo(int D, int HP, int RB, int OS) { return RB + OS + (D - 1) * (HP + RB + OS); }   // waited at the top of block t
 constexpr int hs_after_residual(int HP, int RB, int OS) { return OS + HP + RB; }                              // waited before the epilogue of t
 
-// R x S taps, CPT k16 steps (16 input channels each) per tap; wave grid MW x NW over (pixel blocks x channel blocks);
-// TM 32-pixel blocks (= two rows of the 16 x 16 output block) and TN 32-channel blocks per wave; MW * TM == 8.
-template <int R, int S, int CPT, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES>
+// R x S taps over pixels of CPP 16-byte chunks (8 channels each): K is the plain (r, s, c) order, so chunk g = (tap g / CPP, channels
+// 8 (g % CPP) ..) and k16 step Q multiplies chunks 2Q (lanes 0-31) and 2Q + 1 (lanes 32-63) -- which may belong to two taps when
+// CPP is odd (HRNet-w40's 40-channel pixels).  Wave grid MW x NW over (pixel blocks x channel blocks); TM 32-pixel blocks (= two
+// rows of the 16 x 16 output block) and TN 32-channel blocks per wave; MW * TM == 8.
+template <int R, int S, int CPP, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
     constexpr int NWV = MW * NW;
     constexpr int HH = 16 + R - 1, HW = 16 + S - 1, HROWS = HH * HW;
-    constexpr int LPR = CPT * 2;                       // 16-byte chunks per halo pixel
-    constexpr int RPP = 512 / LPR;                     // halo pixels filled per DMA pass
-    constexpr int HP = (HROWS + RPP - 1) / RPP;        // DMA instructions per halo image and thread
-    constexpr int SLOT = HP * RPP * LPR * 16;          // bytes of one halo image (padded to whole passes)
+    constexpr int NCH = R * S * CPP;                   // 16-byte chunks of the reduction
+    constexpr int HP = (HROWS * CPP + 511) / 512;      // DMA instructions per halo image and thread
+    constexpr int SLOT = HP * 8192;                    // bytes of one halo image (padded to whole passes)
     constexpr int D = NSLOT - 1;
     constexpr int RB = HAS_RES ? TM * TN * 2 : 0, OS = TM * TN * 2;
     constexpr int ZW = TM * TN * 2 * 1024;
-    constexpr int NSTEP = R * S * CPT;
-    static_assert(NWV == 8 && MW * TM == 8 && (LPR == 8 || LPR == 2), "eight waves over eight 32-pixel blocks; 64- or 16-channel pixels");
+    constexpr int NSTEP = (NCH + 1) / 2;
+    constexpr bool SWZ = CPP == 8;                     // 128-byte pixels: XOR swizzle; 80- / 32-byte pixels are conflict-free as they lie
+    static_assert(NWV == 8 && MW * TM == 8, "eight waves over eight 32-pixel blocks");
     extern __shared__ __attribute__((aligned(16))) char hsm[];
     char *zones = hsm + NSLOT * SLOT;                  // [2][NWV][ZW]
 
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
     const _Float16 *Rin = reinterpret_cast<const _Float16 *>(p.res);
     _Float16 *Out = reinterpret_cast<_Float16 *>(p.out);
 
-    // ---- weights -> registers, once: block b, step Q (tap Q / CPT, channels 16 (Q % CPT) ..): 8 halfs k = 16 Q + 8 kh .. of row
+    // ---- weights -> registers, once: block b, step Q: the 8 halfs k = 16 Q + 8 kh .. of row
     // swap23(l31) (conv_igemm's transposed-output convention: registers 8j .. 8j+7 are eight consecutive channels)
     const int wl31 = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
     hf16x8 wreg[TN][NSTEP];
@@ -95,16 +97,14 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- halo DMA roles, block-invariant: pass i fills halo pixel hp = i * RPP + tid / LPR, chunk tid % LPR (the chunk it
-    // FETCHES is XOR-swizzled so that the lane-linear LDS image is conflict-free for the fragment reads)
-    const int hchunk = tid % LPR;
-    int hyx[HP];   // (row << 8 | column) of the halo pixel; rows past the halo get row 200: always out of the image -> zero page
+    // ---- halo DMA roles, block-invariant: pass i moves 16-byte unit L = 512 i + tid of the image = chunk L % CPP of halo pixel
+    // L / CPP (with 128-byte pixels the chunk it FETCHES is XOR-swizzled so that the lane-linear LDS image is conflict-free)
+    int hyx[HP];   // row << 16 | column << 8 | source chunk; units past the halo get row 200: always out of the image -> zero page
 #pragma unroll
     for (int i = 0; i < HP; ++i) {
-        const int hp = i * RPP + tid / LPR;
-        hyx[i] = ((hp < HROWS ? hp / HW : 200) << 8) | (hp - (hp / HW) * HW);
+        const int L = 512 * i + tid, hp = L / CPP, ch = L - hp * CPP;
+        hyx[i] = ((hp < HROWS ? hp / HW : 200) << 16) | ((hp - (hp / HW) * HW) << 8) | (SWZ ? (ch ^ ((hp >> 1) & 7)) : ch);
     }
-    const int kqs = LPR == 8 ? (hchunk ^ ((tid >> 4) & 7)) : hchunk;   // (pixel >> 1) & 7 == (tid >> 4) & 7: RPP = 64 is a multiple of 16
 
     auto block_origin = [&](int tt, int &n, int &by, int &bx) {
         const int g = (int)blockIdx.x + tt * (int)gridDim.x;
@@ -120,9 +120,9 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
         char *dst = hsm + (((tt % NSLOT) + NSLOT) % NSLOT) * SLOT + wave * 1024;
 #pragma unroll
         for (int i = 0; i < HP; ++i) {
-            const int iy = by * 16 - p.pad_h + (hyx[i] >> 8), ix = bx * 16 - p.pad_w + (hyx[i] & 255);
-            const bool ok = live && (hyx[i] >> 8) < 200 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const _Float16 *src = ok ? Ain + ((size_t)(n * p.H + iy) * p.W + ix) * p.lda + 8 * kqs : zero16;
+            const int iy = by * 16 - p.pad_h + (hyx[i] >> 16), ix = bx * 16 - p.pad_w + ((hyx[i] >> 8) & 255);
+            const bool ok = live && (hyx[i] >> 16) < 200 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const _Float16 *src = ok ? Ain + ((size_t)(n * p.H + iy) * p.W + ix) * p.lda + 8 * (hyx[i] & 255) : zero16;
             asm volatile("" : "+v"(src));   // ONE DMA instruction per schedule entry
             HMV_HGLDS16(src, dst + i * 8192);
         }
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const _Float16 *src = live ? Rin + pix * p.ldr + n0 + 32 * b + 16 * j + 8 * kh : zero16;
+                        const int col = n0 + 32 * b + 16 * j + 8 * kh;
+                        const _Float16 *src = (live && col < p.Cout) ? Rin + pix * p.ldr + col : zero16;
                         asm volatile("" : "+v"(src));
                         HMV_HGLDS16(src, z + ((a * TN + b) * 2 + j) * 1024);
                     }
@@ -186,32 +187,36 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
         issue_halo(tt + D);                                                   // ... whose slot takes halo(tt + D)
         issue_R(tt + 1);
         const char *himg = hsm + (tt % NSLOT) * SLOT;
-        // the fragment addresses are block-invariant: left visible, the compiler hoists all R * S * CPT * TM of them out of the
-        // block loop and spills them (the weights hold 144 registers).  An opaque zero makes them this block's own arithmetic.
+        // the fragment addresses are block-invariant: left visible, the compiler hoists all of them out of the block loop and
+        // spills them (the weights hold up to 144 registers).  An opaque zero makes them this block's own arithmetic.
         int hz;
         asm volatile("v_mov_b32 %0, 0" : "=v"(hz));
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+        for (int Q = 0; Q < NSTEP; ++Q) {
+            // chunk of lanes 0-31 / 32-63 (a chunk past the reduction's end multiplies zero weights: any finite pixel will do)
+            constexpr int dummy = 0;
+            const int gA = 2 * Q < NCH ? 2 * Q : dummy, gB = 2 * Q + 1 < NCH ? 2 * Q + 1 : dummy;
+            const int tA = gA / CPP, cA = gA - tA * CPP, tB = gB / CPP, cB = gB - tB * CPP;
+            const int oA = (tA / S) * HW + tA % S, oB = (tB / S) * HW + tB % S;   // halo pixel offset of the tap
+            hf16x8 px[TM];
 #pragma unroll
-            for (int s = 0; s < S; ++s)
-#pragma unroll
-                for (int j = 0; j < CPT; ++j) {
-                    hf16x8 px[TM];
-#pragma unroll
-                    for (int a = 0; a < TM; ++a) {
-                        const int h = hb[a] + hz + r * HW + s;
-                        const int ch = LPR == 8 ? ((2 * j + kh) ^ ((h >> 1) & 7)) : kh;
-                        px[a] = *reinterpret_cast<const hf16x8 *>(himg + (h * LPR + ch) * 16);
-                    }
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int b = 0; b < TN; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[b][(r * S + s) * CPT + j], px[a], acc[a][b], 0, 0, 0);
-                    // keep the scheduler from hoisting every tap's address arithmetic and fragment reads to the top of the block
-                    // (the weights already hold 144 registers: that hoisting spilled 40)
-                    if (j == CPT - 1) __builtin_amdgcn_sched_barrier(0);
+            for (int a = 0; a < TM; ++a) {
+                if constexpr (SWZ) {   // CPP == 8: both chunks belong to one tap
+                    const int h = hb[a] + hz + oA;
+                    px[a] = *reinterpret_cast<const hf16x8 *>(himg + (h * 8 + ((cA + kh) ^ ((h >> 1) & 7))) * 16);
+                } else {
+                    const int u = (hb[a] + hz) * CPP + (kh ? oB * CPP + cB : oA * CPP + cA);
+                    px[a] = *reinterpret_cast<const hf16x8 *>(himg + u * 16);
                 }
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[b][Q], px[a], acc[a][b], 0, 0, 0);
+            // keep the scheduler from hoisting every step's address arithmetic and fragment reads to the top of the block
+            if ((Q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- epilogue
         if constexpr (HAS_RES) hs_wait_vm<hs_after_residual(HP, RB, OS)>();
         int n, by, bx;
@@ -230,7 +235,9 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
                     hf16x8 hv;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + (float)rr[u], lo);
-                    _Float16 *dst = orow + 32 * b + 16 * j;   // (every block of a launch is whole: H and W are multiples of 16)
+                    // (every block of a launch is whole: H and W are multiples of 16; channel groups past Cout -- 40-channel
+                    // layers on 64 weight rows -- go to the trash page: every lane stores, the counts above rely on it)
+                    _Float16 *dst = (n0 + 32 * b + 16 * j + 8 * kh) < p.Cout ? orow + 32 * b + 16 * j : trash;
                     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(hv) : "memory");
                 }
         }
@@ -242,10 +249,12 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
 static int g_hs_mode = -1;   // -1: the launcher's rule (HMV_NO_HS=1 disables it); 0 never; 1 whenever supported (op-level tests)
 void conv_hs_set_mode(int mode) { g_hs_mode = mode; }
 
-// 0: no instantiation; 1: 3x3 pad 1, 64 -> 64 channels; 2: the 4x4 space-to-depth stem, 16 -> 64 channels
+// 0: no instantiation; 1: 3x3 pad 1, 64 -> 64 channels; 2: the 4x4 space-to-depth stem, 16 -> 64 channels; 3: 3x3 pad 1, 40 -> 40
+// channels in the plain (r, s, c) K order (HRNet-w40's highest-resolution branch, hrnet.py:96-221)
 static int hs_kind(const ConvParams &p) {
     if (p.R == 3 && p.S == 3 && p.pad_h == 1 && p.pad_w == 1 && p.Cin == 64 && p.Cout == 64 && p.Kpad == 576) return 1;
     if (p.R == 4 && p.S == 4 && p.pad_h == 2 && p.pad_w == 2 && p.Cin == 16 && p.Cout == 64 && p.Kpad == 256 && !p.res) return 2;
+    if (p.R == 3 && p.S == 3 && p.pad_h == 1 && p.pad_w == 1 && p.Cin == 40 && p.Cout == 40 && p.Kpad == 384 && !p.rd_cout) return 3;
     return 0;
 }
 
@@ -255,20 +264,21 @@ bool conv_hs_supported(const ConvParams &p) {
     if (g_hs_mode == 0 || (g_hs_mode < 0 && off)) return false;
     if (!hs_kind(p) || !p.in_f16 || !p.out_f16 || (p.res && !p.res_f16)) return false;
     if (p.stride != 1 || p.up || p.in2 || p.ksl > 1 || p.phases > 1 || p.Ho != p.H || p.Wo != p.W || (p.H & 15) || (p.W & 15)) return false;
-    if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out || p.fill) return false;
+    if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out) return false;
+    if (p.fill && p.ldc != p.Cout) return false;   // (pad columns to clear: conv_igemm's epilogue does that)
     if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
     if ((p.lda ? p.lda : p.Cin) != p.Cin || ((p.ldw ? p.ldw : p.Kpad) & 7) || (p.ldc & 7) || (p.res && (p.ldr & 7))) return false;
     if (g_hs_mode > 0) return true;
     return (long long)p.N * (p.H >> 4) * (p.W >> 4) >= 4 * 256;   // at least four blocks per workgroup
 }
 
-template <int R, int S, int CPT, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES>
+template <int R, int S, int CPP, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES>
 static hipError_t launch_hs_one(const ConvParams &p, hipStream_t s) {
-    constexpr int HROWS = (16 + R - 1) * (16 + S - 1), LPR = CPT * 2, RPP = 512 / LPR, HP = (HROWS + RPP - 1) / RPP;
-    constexpr size_t lds = (size_t)NSLOT * HP * RPP * LPR * 16 + (HAS_RES ? (size_t)2 * 8 * TM * TN * 2 * 1024 : 0);
+    constexpr int HROWS = (16 + R - 1) * (16 + S - 1), HP = (HROWS * CPP + 511) / 512;
+    constexpr size_t lds = (size_t)NSLOT * HP * 8192 + (HAS_RES ? (size_t)2 * 8 * TM * TN * 2 * 1024 : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool configured[64] = {};
-    auto kern = conv_hs_f16<R, S, CPT, TM, TN, MW, NW, NSLOT, HAS_RES>;
+    auto kern = conv_hs_f16<R, S, CPP, TM, TN, MW, NW, NSLOT, HAS_RES>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
@@ -286,13 +296,20 @@ hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name)
         case 1:
             if (p.res) {
                 if (name) *name = "conv_hs_f16<3x3,64->64,res>";
-                return launch_hs_one<3, 3, 4, 2, 1, 4, 2, 2, true>(p, s);
+                return launch_hs_one<3, 3, 8, 2, 1, 4, 2, 2, true>(p, s);
             }
             if (name) *name = "conv_hs_f16<3x3,64->64>";
-            return launch_hs_one<3, 3, 4, 2, 1, 4, 2, 3, false>(p, s);   // no landing zones: three halo images (two in flight)
+            return launch_hs_one<3, 3, 8, 2, 1, 4, 2, 3, false>(p, s);   // no landing zones: three halo images (two in flight)
         case 2:
             if (name) *name = "conv_hs_f16<4x4,16->64>";
-            return launch_hs_one<4, 4, 1, 2, 1, 4, 2, 4, false>(p, s);
+            return launch_hs_one<4, 4, 2, 2, 1, 4, 2, 4, false>(p, s);
+        case 3:   // 40-channel pixels: 26 KB halo images
+            if (p.res) {
+                if (name) *name = "conv_hs_f16<3x3,40->40,res>";
+                return launch_hs_one<3, 3, 5, 2, 1, 4, 2, 3, true>(p, s);
+            }
+            if (name) *name = "conv_hs_f16<3x3,40->40>";
+            return launch_hs_one<3, 3, 5, 2, 1, 4, 2, 4, false>(p, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -567,6 +567,10 @@ int hmv_finalize_weights(hmv_handle h) {
         for (int b = 0; b < 2; ++b)
             rdb[b] = 3 * hr.ch[b] <= 256 && hr.ch[b] % 32 != 0 && hr.ch[b] % 4 == 0 && 128 % (c.width / (4 << b)) == 0 && !L.split &&
                      !getenv("HMV_NO_ROWSUM");
+        // fp16 path, 40-channel branch on frames whose H/4 x W/4 map tiles into 16 x 16 blocks: plain (r, s, c) packing instead, so
+        // that the weight-stationary halo-streaming kernel (conv_hs.hip: 1.9 -> ~4 TB/s on these layers) takes the large batches
+        // and conv_igemm's dense mode -- same K order, same bits -- the small ones.  Decided by the configuration, never by the batch.
+        if (h16 && !L.split && hr.ch[0] == 40 && c.height % 64 == 0 && c.width % 64 == 0 && !getenv("HMV_NO_HS")) rdb[0] = false;
         const bool rd0 = rdb[0];
         L.conv(hr.conv1, "stem.conv1", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 3, 3, /*cin_pad=*/h16 ? 8 : 4, h16);
         L.conv(hr.conv2, "stem.conv2", "backbone.conv2.weight", "", "backbone.bn2", 64, 64, 3, 3, 0, h16);

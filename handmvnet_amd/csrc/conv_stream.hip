@@ -290,11 +290,21 @@ static hipError_t launch_stream_one(ConvParams p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// shapes with an instantiation: (K, BN) = (256, 512), (128, 512), (64, 256), residual-bearing (Bottleneck conv3)
-static int stream_bn(const ConvParams &p) {
-    if (p.Kpad == 256 || p.Kpad == 128) return 512;
-    if (p.Kpad == 64) return 256;
-    return 0;
+// shapes with an instantiation.  Residual-bearing (Bottleneck conv3): (K, BN) = (256, 512), (128, 512), (64, 256).  Without a residual
+// (the squeezing conv1 of layer1 / layer2, resnet.py:128-130): (K, Cout) = (256, 64), (512, 128), (256, 128), all of Cout in one slice.
+// Returns the channel-slice width BN (0: none) and the pixel-tile height through *bm.
+static int stream_bn(const ConvParams &p, int *bm = nullptr) {
+    int bn = 0, m = 0;
+    if (p.res) {
+        if (p.Kpad == 256 || p.Kpad == 128) { bn = 512; m = 64; }
+        else if (p.Kpad == 64) { bn = 256; m = 128; }
+    } else {
+        if (p.Kpad == 256 && p.Cout == 64) { bn = 64; m = 256; }
+        else if (p.Kpad == 512 && p.Cout == 128) { bn = 128; m = 128; }
+        else if (p.Kpad == 256 && p.Cout == 128) { bn = 128; m = 128; }
+    }
+    if (bm) *bm = m;
+    return bn;
 }
 
 // -1: the launcher's rule (HMV_NO_STREAM=1 in the environment disables the kernel for A/B runs); 0: never; 1: whenever the shape
@@ -309,14 +319,15 @@ bool conv_stream_supported(const ConvParams &p) {
     if (min_env < 0) { const char *e = getenv("HMV_STREAM_MIN_TILES"); min_env = e ? atoi(e) : 4; }
     if (g_stream_mode == 0 || (g_stream_mode < 0 && off)) return false;
     const int min_tiles = g_stream_mode > 0 ? 0 : min_env;
-    const int bn = stream_bn(p);
-    if (!bn || !p.in_f16 || !p.out_f16 || !p.res || !p.res_f16) return false;
+    int bm = 0;
+    const int bn = stream_bn(p, &bm);
+    if (!bn || !p.in_f16 || !p.out_f16 || (p.res && !p.res_f16)) return false;
     if (p.R != 1 || p.S != 1 || p.stride != 1 || p.pad_h || p.pad_w || p.up || p.in2 || p.ksl > 1 || p.phases > 1) return false;
     if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out || p.fill) return false;
     if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
     if (p.Cin != p.Kpad || p.K != p.Kpad || p.Cout % bn != 0 || 32 % (p.Cout / bn) != 0) return false;
-    if ((p.lda ? p.lda : p.Cin) % 8 || (p.ldw ? p.ldw : p.Kpad) % 8 || p.ldc % 8 || p.ldr % 8) return false;
-    const int bm = bn == 512 ? 64 : 128, streams = 256 / (p.Cout / bn);
+    if ((p.lda ? p.lda : p.Cin) % 8 || (p.ldw ? p.ldw : p.Kpad) % 8 || p.ldc % 8 || (p.res && p.ldr % 8)) return false;
+    const int streams = 256 / (p.Cout / bn);
     return (long long)(p.M + bm - 1) / bm >= (long long)min_tiles * streams;
 }
 
@@ -336,6 +347,18 @@ hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **n
         case 100: if (p.Kpad == 256) return launch_stream_one<__VA_ARGS__, true, true, 0>(p, s);            \
                   return launch_stream_one<__VA_ARGS__, true, false, 0>(p, s);                              \
         default: return launch_stream_one<__VA_ARGS__, true, false, 0>(p, s);                               \
+    }
+    if (!p.res) {   // the squeezing 1x1 convs: no landing zones, the whole LDS is the pixel ring (128 KB, seven pieces ahead)
+        if (p.Kpad == 256 && p.Cout == 64) {
+            if (name) *name = "conv_stream_f16<256x64,k256>";
+            return launch_stream_one<1, 2, 8, 1, 4, 4, false>(p, s);
+        }
+        if (p.Kpad == 512) {
+            if (name) *name = "conv_stream_f16<128x128,k512>";
+            return launch_stream_one<2, 1, 2, 4, 8, 8, false>(p, s);
+        }
+        if (name) *name = "conv_stream_f16<128x128,k256>";
+        return launch_stream_one<1, 2, 4, 2, 4, 8, false>(p, s);
     }
     if (p.Kpad == 256) {
         if (name) *name = "conv_stream_f16<64x512,k256,res>";

@@ -257,7 +257,10 @@ STREAM_SHAPES = [(4, 32, 32, 256, 1024, 1, 1, 0, True, True), (3, 17, 19, 256, 5
                  (64, 32, 32, 256, 1024, 1, 1, 0, True, True), (8, 32, 32, 128, 512, 1, 1, 0, True, True),
                  (1, 33, 31, 128, 1024, 1, 1, 0, True, True), (40, 32, 32, 128, 512, 1, 1, 0, True, False),
                  (4, 64, 64, 64, 256, 1, 1, 0, True, True), (2, 30, 35, 64, 512, 1, 1, 0, True, False),
-                 (40, 64, 64, 64, 256, 1, 1, 0, True, True)]
+                 (40, 64, 64, 64, 256, 1, 1, 0, True, True),
+                 # without a residual: the squeezing conv1 shapes (K, Cout) = (256, 64), (512, 128), (256, 128)
+                 (4, 64, 64, 256, 64, 1, 1, 0, False, True), (3, 17, 19, 256, 64, 1, 1, 0, False, False), (40, 64, 64, 256, 64, 1, 1, 0, False, True),
+                 (8, 32, 32, 512, 128, 1, 1, 0, False, True), (1, 33, 31, 512, 128, 1, 1, 0, False, True), (12, 64, 64, 256, 128, 1, 1, 0, False, True)]
 
 
 # 1x1 convs without a residual on the phase-interleaved 256 x 256 tile (conv_gemm8.hip): K from 2 to 16 k-steps, ragged pixel and
@@ -305,7 +308,7 @@ def test_stream_kernel_is_bit_identical(shape):
     kernel the launcher picks), and both against torch fp64 at fp16 accuracy."""
     a, ka, (x, w, b, res, relu) = _run_conv_f16(shape, 2)
     c, kc, _ = _run_conv_f16(shape, 1)
-    want = "conv_hs_f16" if shape[5] == 3 else ("conv_stream_f16" if shape[8] else "conv_gemm8_f16")
+    want = "conv_hs_f16" if shape[5] == 3 else ("conv_stream_f16" if shape in STREAM_SHAPES else "conv_gemm8_f16")
     assert ka.startswith(want) and kc.startswith("conv_igemm_f16"), (ka, kc)
     assert torch.isfinite(a.float()).all()
     assert torch.equal(a.view(torch.int16), c.view(torch.int16)), (ka, kc, (a.float() - c.float()).abs().max())

@@ -93,7 +93,9 @@ static_assert(sched_after_piece(4, 3, 1, 8, 2, 8, 0) == 2 + 3 + 3 + 8 && sched_a
 // TM x TN 32x32 blocks per wave, MW x NW waves (pixels x channels), NP 64-channel pieces of reduction, NSLOT ring slots.
 // SPREAD: the next tile's residual DMAs go out RB / NP per piece step instead of all at step 0 (a smoother request stream);
 // NT: 0 default cache policy, 1 residual rows non-temporal (read once), 2 pixel pieces too
-template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool SPREAD = false, int NT_ = 0>
+// DUAL: the reduction is the concatenation [first source | second source] (conv3 + downsample of a layer's first Bottleneck as one
+// GEMM, ConvParams::in2): pieces past ksplit come from the second tensor at pixel (ho * stride2, wo * stride2)
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool SPREAD = false, int NT_ = 0, bool DUAL = false>
 __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(const ConvParams p) {
     constexpr int NWV = MW * NW, NT = 64 * NWV;
     constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
     constexpr int ZW = TM * TN * 2 * 1024;       // bytes of one wave's residual landing zone
     constexpr int NFAKE = (D + NP - 1) / NP;     // tiles "before the first" whose schedule the prologue replays
     static_assert(NT == 512 && BM % 64 == 0 && PA >= 1, "eight waves; whole DMA passes per piece");
-    static_assert((NP & (NP - 1)) == 0 && (NSLOT & (NSLOT - 1)) == 0 && NSLOT >= 2, "powers of two");
+    static_assert((NSLOT & (NSLOT - 1)) == 0 && NSLOT >= 2, "a power of two");
     extern __shared__ __attribute__((aligned(16))) char ssm[];
     _Float16 *sA = reinterpret_cast<_Float16 *>(ssm);            // [NSLOT][BM][64]
     char *zones = ssm + NSLOT * BM * 128;                         // [2][NWV][ZW]
@@ -148,13 +150,24 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
 
     // issue the pixel DMAs of piece G (in this workgroup's own piece sequence; outside [0, ntl * NP) -> zero page)
     auto issue_A = [&](int G) {
-        const int tt = G >= 0 ? G / NP : -1, jj = G & (NP - 1), slot = G & (NSLOT - 1);
+        const int tt = G >= 0 ? G / NP : -1, jj = G >= 0 ? G - tt * NP : 0, slot = G & (NSLOT - 1);
         const int mt = stream + tt * nstreams;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int m = mt * BM + i * 64 + arow;
             const bool ok = tt >= 0 && tt < ntl && m < p.M;
-            const _Float16 *src = ok ? Ain + (size_t)m * p.lda + jj * 64 + 8 * kqs : zero16;
+            const _Float16 *src = zero16;
+            if constexpr (DUAL) {
+                if (ok && jj * 64 >= p.ksplit) {
+                    const int hw = p.Ho * p.Wo, n = m / hw, rem = m - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    src = reinterpret_cast<const _Float16 *>(p.in2) + ((size_t)(n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.lda2 +
+                          (jj * 64 - p.ksplit) + 8 * kqs;
+                } else if (ok) {
+                    src = Ain + (size_t)m * p.lda + jj * 64 + 8 * kqs;
+                }
+            } else if (ok) {
+                src = Ain + (size_t)m * p.lda + jj * 64 + 8 * kqs;
+            }
             asm volatile("" : "+v"(src));   // ONE DMA instruction per schedule entry: keep the select out of the control flow
             if constexpr (NT_ >= 2) HMV_SGLDS16_NT(src, sA + ((slot * BM + i * 64 + wave * 8) * 64));
             else HMV_SGLDS16(src, sA + ((slot * BM + i * 64 + wave * 8) * 64));
@@ -270,13 +283,13 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
 }
 
 // ====================================================================== host side
-template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool SPREAD = false, int NT_ = 0>
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool SPREAD = false, int NT_ = 0, bool DUAL = false>
 static hipError_t launch_stream_one(ConvParams p, hipStream_t s) {
     constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW, NWV = MW * NW;
     constexpr size_t lds = (size_t)NSLOT * BM * 128 + (HAS_RES ? (size_t)2 * NWV * TM * TN * 2 * 1024 : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool configured[64] = {};
-    auto kern = conv_stream_f16<TM, TN, MW, NW, NP, NSLOT, HAS_RES, SPREAD, NT_>;
+    auto kern = conv_stream_f16<TM, TN, MW, NW, NP, NSLOT, HAS_RES, SPREAD, NT_, DUAL>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
@@ -295,7 +308,10 @@ static hipError_t launch_stream_one(ConvParams p, hipStream_t s) {
 // Returns the channel-slice width BN (0: none) and the pixel-tile height through *bm.
 static int stream_bn(const ConvParams &p, int *bm = nullptr) {
     int bn = 0, m = 0;
-    if (p.res) {
+    if (p.in2) {   // conv3 + downsample of layer1.0 (64 + 64 -> 256) and layer2.0 (128 + 256 -> 512, strided second source)
+        if (!p.res && p.Kpad == 128 && p.ksplit == 64 && p.Cout == 256) { bn = 256; m = 128; }
+        else if (!p.res && p.Kpad == 384 && p.ksplit == 128 && p.Cout == 512) { bn = 256; m = 64; }
+    } else if (p.res) {
         if (p.Kpad == 256 || p.Kpad == 128) { bn = 512; m = 64; }
         else if (p.Kpad == 64) { bn = 256; m = 128; }
     } else {
@@ -322,10 +338,11 @@ bool conv_stream_supported(const ConvParams &p) {
     int bm = 0;
     const int bn = stream_bn(p, &bm);
     if (!bn || !p.in_f16 || !p.out_f16 || (p.res && !p.res_f16)) return false;
-    if (p.R != 1 || p.S != 1 || p.stride != 1 || p.pad_h || p.pad_w || p.up || p.in2 || p.ksl > 1 || p.phases > 1) return false;
+    if (p.R != 1 || p.S != 1 || p.stride != 1 || p.pad_h || p.pad_w || p.up || p.ksl > 1 || p.phases > 1) return false;
+    if (p.in2 && ((p.lda2 & 7) || (p.ksplit & 63) || p.lda != p.ksplit)) return false;
     if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out || p.fill) return false;
     if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
-    if (p.Cin != p.Kpad || p.K != p.Kpad || p.Cout % bn != 0 || 32 % (p.Cout / bn) != 0) return false;
+    if ((!p.in2 && p.Cin != p.Kpad) || p.K != p.Kpad || p.Cout % bn != 0 || 32 % (p.Cout / bn) != 0) return false;
     if ((p.lda ? p.lda : p.Cin) % 8 || (p.ldw ? p.ldw : p.Kpad) % 8 || p.ldc % 8 || (p.res && p.ldr % 8)) return false;
     const int streams = 256 / (p.Cout / bn);
     return (long long)(p.M + bm - 1) / bm >= (long long)min_tiles * streams;
@@ -347,6 +364,14 @@ hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **n
         case 100: if (p.Kpad == 256) return launch_stream_one<__VA_ARGS__, true, true, 0>(p, s);            \
                   return launch_stream_one<__VA_ARGS__, true, false, 0>(p, s);                              \
         default: return launch_stream_one<__VA_ARGS__, true, false, 0>(p, s);                               \
+    }
+    if (p.in2) {
+        if (p.Kpad == 128) {
+            if (name) *name = "conv_stream_f16<128x256,k128,dual>";
+            return launch_stream_one<2, 2, 2, 4, 2, 8, false, false, 0, true>(p, s);
+        }
+        if (name) *name = "conv_stream_f16<64x256,k384,dual>";
+        return launch_stream_one<2, 1, 1, 8, 6, 8, false, false, 0, true>(p, s);
     }
     if (!p.res) {   // the squeezing 1x1 convs: no landing zones, the whole LDS is the pixel ring (128 KB, seven pieces ahead)
         if (p.Kpad == 256 && p.Cout == 64) {

@@ -41,7 +41,9 @@ def family(name: str) -> str:
     m = re.match(r"(?:void )?(?:hmv::)?conv_stream_f16<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, (true|false)", name)
     if m:
         tm, tn, mw, nw, np_ = (int(m.group(i)) for i in range(1, 6))
-        return f"conv_stream_f16<{32 * tm * mw}x{32 * tn * nw},k{64 * np_}" + (",res>" if m.group(6) == "true" else ">")
+        dual = re.search(r", (true|false)>\(", name)
+        tail = ",res>" if m.group(6) == "true" else (",dual>" if dual and dual.group(1) == "true" and name.count(",") >= 9 else ">")
+        return f"conv_stream_f16<{32 * tm * mw}x{32 * tn * nw},k{64 * np_}" + tail
     m = re.match(r"(?:void )?(?:hmv::)?conv_gemm8_f16<(true|false)>", name)
     if m:
         return "conv_gemm8_f16<256x256,1x1" + (",dual>" if m.group(1) == "true" else ">")

@@ -1,6 +1,8 @@
 // misc_kernels.hip -- the memory-bound / small kernels around the conv-GEMM family.
 // All are HBM- or latency-bound; they are written for coalesced 16-byte accesses and
 // 64-lane wave reductions (gfx950 wavefront = 64).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace hmv {
@@ -351,8 +353,96 @@ __global__ void soft_argmax_kernel(const float *__restrict__ hm, int ld, int h, 
         crop_img[2 * wid + 1] = cy * image_size / heatmap_size;
     }
 }
+// The same op, one workgroup per FRAME (heat maps of up to 32 x 32 pixels: the ResNet50-paper head).  The channels-last logits
+// [h * w][32] are read as whole 128-byte pixel rows -- 8 lanes x 16 bytes per pixel, 32 pixels per pass -- instead of one
+// 4-byte column per lane and pixel: the wave-per-(frame, joint) kernel above moved 402 MB per cfg-3 launch for 34 MB of logits
+// (every wave pulls whole cache lines for one float each).  Two passes (channel maxima, then the three sums), the second from
+// L2; per-thread partials over its pixel slot, then a fixed-order reduction over the 32 slots through LDS.  Which kernel runs
+// depends on the heat-map size alone, never on the batch.
+__global__ __launch_bounds__(256) void soft_argmax_frame_kernel(const float *__restrict__ hm, int h, int w, float *coords, float *crop_img,
+                                                                float image_size, float heatmap_size, float *hm_nchw) {
+    __shared__ float red[4][32][33];   // [max | se | sx | sy][pixel slot][channel]
+    const int n = blockIdx.x, tid = threadIdx.x, slot = tid >> 3, c4 = tid & 7, hw = h * w;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(hm + (size_t)n * hw * 32) + c4;
+    const bool act = c4 < 6;   // channels 0 .. 23 (21 joints); the last two vectors of a pixel row are padding
+    f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    // (eight pixels per trip, every load issued before the first use: a load-use-load loop pays a memory round trip per pixel)
+    for (int p0 = slot; p0 < hw; p0 += 256) {
+        f32x4 raw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 32 * u;
+            raw[u] = (act && p < hw) ? src[(size_t)p * 8] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 32 * u;
+            if (hm_nchw && act && p < hw) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * c4 + e < 21) hm_nchw[((size_t)n * 21 + 4 * c4 + e) * hw + p] = raw[u][e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], raw[u][e] * 1000.0f);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[0][slot][4 * c4 + e] = mx[e];
+    __syncthreads();
+    if (tid < 32) {
+        float m = red[0][0][tid];
+        for (int q = 1; q < 32; ++q) m = fmaxf(m, red[0][q][tid]);
+        red[0][0][tid] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mx[e] = red[0][0][4 * c4 + e];
+    f32x4 se = {0.f, 0.f, 0.f, 0.f}, sx = se, sy = se;
+    for (int p0 = slot; p0 < hw; p0 += 256) {
+        f32x4 raw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 32 * u;
+            raw[u] = (act && p < hw) ? src[(size_t)p * 8] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // exp(-inf) = 0
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 32 * u, y = p / w, x = p - y * w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ex = act ? expf(raw[u][e] * 1000.0f - mx[e]) : 0.f;
+                se[e] += ex;
+                sx[e] += ex * (float)x;
+                sy[e] += ex * (float)y;
+            }
+        }
+    }
+    __syncthreads();   // red[0][0][*] has been read by everyone
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[1][slot][4 * c4 + e] = se[e];
+        red[2][slot][4 * c4 + e] = sx[e];
+        red[3][slot][4 * c4 + e] = sy[e];
+    }
+    __syncthreads();
+    if (tid < 21) {
+        float a = 0.f, bx = 0.f, by = 0.f;
+        for (int q = 0; q < 32; ++q) { a += red[1][q][tid]; bx += red[2][q][tid]; by += red[3][q][tid]; }
+        const float cx = bx / a, cy = by / a;
+        const int wid = n * 21 + tid;
+        coords[2 * wid] = cx;
+        coords[2 * wid + 1] = cy;
+        crop_img[2 * wid] = cx * image_size / heatmap_size;  // handmvnet.py:252
+        crop_img[2 * wid + 1] = cy * image_size / heatmap_size;
+    }
+}
 hipError_t launch_soft_argmax(const float *hm, int ld, int N, int h, int w, float *coords, float *crop_img,
                               float image_size, float heatmap_size, float *hm_nchw, hipStream_t s) {
+    static const bool no_frame = getenv("HMV_SOFTARGMAX_WAVE") != nullptr;   // development knob (A/B runs)
+    if (!no_frame && ld == 32 && h * w <= 1024) {
+        hipLaunchKernelGGL(soft_argmax_frame_kernel, dim3(N), dim3(256), 0, s, hm, h, w, coords, crop_img, image_size, heatmap_size, hm_nchw);
+        return hipGetLastError();
+    }
     const int total = N * 21;
     hipLaunchKernelGGL(soft_argmax_kernel, dim3((total + 3) / 4), dim3(256), 0, s, hm, ld, h, w, total, coords, crop_img,
                        image_size, heatmap_size, hm_nchw);

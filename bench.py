@@ -104,7 +104,7 @@ def cpu_baseline(cfg, sd, size, model, dev, min_seconds=10.0):
         orc.forward(x, bbox, intr)
         n += 1
         el = time.perf_counter() - t0
-        if el >= min_seconds or n >= 50:
+        if el >= min_seconds or n >= 5000:   # a bounded sample: ~min_seconds of CPU work, whatever the shape
             break
     out = model(torch.from_numpy(x).to(dev), torch.from_numpy(bbox).to(dev), {"intrinsic": torch.from_numpy(intr).to(dev)})
     torch.cuda.synchronize()

@@ -52,3 +52,41 @@ def test_child_failure_is_the_parents_exit_status():
 def test_gpus_must_match_world_size_under_torchrun():
     r = _run(["--gpus", "4", "--launch-check"], env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+
+
+def test_workloads_cover_the_baseline_configs_and_the_lq_bench_config_is_warning_free():
+    """bench.py names BASELINE.json configs[0..2] (cfg1 = HO3D_HandMvNet.yaml's B1 x V4 x 128^2, cfg2, cfg3); the learnable-query
+    bench configuration leaves out the keys that module ignores (no UserWarning from config_from_params)."""
+    import warnings
+    sys.path.insert(0, ROOT)
+    import bench
+    from handmvnet_amd.spec import config_from_params
+    assert bench.WORKLOADS["cfg1"] == ("50_paper", [1024], 4, 1, 128)
+    assert bench.WORKLOADS["cfg2"][2:] == (4, 8, 256) and bench.WORKLOADS["cfg3"][2:] == (8, 32, 256)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        cfg = config_from_params(*bench.params("50_paper", [1024], 8, 32, 256, "cross_attn_learnable_query"))
+    assert cfg.learnable_query
+
+
+def test_forward_block_reports_step_floors_for_the_fp16_modes():
+    sys.path.insert(0, ROOT)
+    import bench
+    fam = {"a": {"bytes": 8e9, "t_hbm": 1e-3, "t_mfma": 2e-4}, "b": {"bytes": 8e9, "t_hbm": 1e-3, "t_mfma": 3e-3}}
+    f32 = bench.forward_block("f32", 157.3e12 * 0.05, 100.0, fam, 1)
+    assert f32["frac_of_f32_mfma_peak"] == 0.5 and "step_floor_ms" not in f32
+    f16 = bench.forward_block("f16", 2.5e15 * 1e-3, 4.0, fam, 1)       # 1 ms of MFMA work, 2 ms of HBM bytes, 4 ms measured
+    assert f16["step_floor_ms"] == {"mfma": 1.0, "hbm@8TB/s": 2.0, "sum_of_per_launch_floors": 4.0} and f16["frac_of_step_floor"] == 0.5
+    assert "frac_of_f32_mfma_peak" not in f16
+
+
+def test_pmc_summary_names_the_round3_kernels_like_the_engine_does():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary as ps
+    assert ps.family("void hmv::conv_stream_f16<2, 2, 1, 8, 4, 4, true, true, 0, false>(hmv::ConvParams)") == "conv_stream_f16<64x512,k256,res>"
+    assert ps.family("void hmv::conv_stream_f16<1, 2, 8, 1, 4, 4, false, false, 0, false>(hmv::ConvParams)") == "conv_stream_f16<256x64,k256>"
+    assert ps.family("void hmv::conv_stream_f16<2, 2, 2, 4, 2, 8, false, false, 0, true>(hmv::ConvParams)") == "conv_stream_f16<128x256,k128,dual>"
+    assert ps.family("void hmv::conv_gemm8_f16<true>(hmv::ConvParams)") == "conv_gemm8_f16<256x256,1x1,dual>"
+    assert ps.family("void hmv::conv_hs_f16<3, 3, 8, 2, 1, 4, 2, 3, false>(hmv::ConvParams)") == "conv_hs_f16<3x3,64->64>"
+    assert ps.family("void hmv::conv_hs_f16<3, 3, 5, 2, 1, 4, 2, 3, true>(hmv::ConvParams)") == "conv_hs_f16<3x3,40->40,res>"
+    assert ps.family("void hmv::conv_hs_f16<4, 4, 2, 2, 1, 4, 2, 4, false>(hmv::ConvParams)") == "conv_hs_f16<4x4,16->64>"

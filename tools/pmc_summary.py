@@ -41,9 +41,15 @@ def family(name: str) -> str:
     m = re.match(r"(?:void )?(?:hmv::)?conv_stream_f16<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, (true|false)", name)
     if m:
         tm, tn, mw, nw, np_ = (int(m.group(i)) for i in range(1, 6))
-        dual = re.search(r", (true|false)>\(", name)
-        tail = ",res>" if m.group(6) == "true" else (",dual>" if dual and dual.group(1) == "true" and name.count(",") >= 9 else ">")
+        targs = name[name.index("<") + 1:name.index(">")].split(", ")
+        tail = ",res>" if m.group(6) == "true" else (",dual>" if len(targs) >= 10 and targs[9] == "true" else ">")
         return f"conv_stream_f16<{32 * tm * mw}x{32 * tn * nw},k{64 * np_}" + tail
+    # conv_hs_f16<R, S, CPP, TM, TN, MW, NW, NSLOT, HAS_RES>: CPP 16-byte chunks (8 channels each) per pixel; 40-channel layers keep 40 outputs
+    m = re.match(r"(?:void )?(?:hmv::)?conv_hs_f16<(\d+), (\d+), (\d+), \d+, (\d+), \d+, (\d+), \d+, (true|false)>", name)
+    if m:
+        r_, s_, cpp, tn, nw = (int(m.group(i)) for i in range(1, 6))
+        cout = 40 if cpp == 5 else 32 * tn * nw
+        return f"conv_hs_f16<{r_}x{s_},{8 * cpp}->{cout}" + (",res>" if m.group(6) == "true" else ">")
     m = re.match(r"(?:void )?(?:hmv::)?conv_gemm8_f16<(true|false)>", name)
     if m:
         return "conv_gemm8_f16<256x256,1x1" + (",dual>" if m.group(1) == "true" else ">")

@@ -1,0 +1,275 @@
+// conv_ht.hip -- 3x3 convolution on TALL tiles (512 pixels x 128 channels) for the fp16 path's MFMA-heavy 3x3 layers.
+//
+// Replaces, where the feature map tiles into 16 x 32 pixel blocks, conv_igemm's 256 x 256 halo tiles for the conv2 of layer2 /
+// layer3's Bottlenecks (/root/reference/src/models/backbones/resnet.py:114-118, 132-134: 3x3, stride 1, padding 1, 128 -> 128 and
+// 256 -> 256 channels at H/8).  Those launches are bound by the bytes a tile moves through the CU's LDS-DMA path, and four fifths of
+// them are WEIGHTS, re-streamed once per tile: 9 taps x 4 chunks x 32 KB = 1 152 of 1 440 KB.  The weight
+// bytes of a layer are (M / BM) K N 2 whatever BN is, while the halo image makes the pixel side cheap (1.27 C bytes per pixel
+// and chunk instead of 9 C), so the tile that moves the fewest bytes per output at 65 536 accumulators is tall: 512 x 128 moves
+// 576 (weights) + 314 (halos) + 128 (output) = 1 018 KB for the same 65 536 outputs, -29 %.
+//
+//   * tile = one 16 x 32 block of one image x 128 output channels; 8 waves as 4 (pixel rows 4 wm .. 4 wm + 3) x 2 (64 channels):
+//     a wave's 32-pixel MFMA block is ONE image row of the block, its lane the column.
+//   * the reduction runs in 32-channel sub-chunks: per sub-chunk the 18 x 34 halo of the block is fetched once (39 KB, two images
+//     in LDS), the nine taps read it at shifted pixels; a k-step = one tap of one sub-chunk = 2 k16 MFMA steps, its weights
+//     [128][32] = 8 KB = ONE 16-byte DMA per thread into a ring of eight stages (seven steps ahead).
+//   * main loop: conv_gemm8's structure with one phase per k-step {fragment reads . DMA . counted `s_waitcnt vmcnt(N)` . barrier .
+//     16 MFMAs . barrier}, the two wave halves one barrier apart, raw barriers, nothing drained inside the loop.  N is static per
+//     tap: the instructions issued after the weight stage that must have landed (one weight DMA per step, one halo DMA on taps 0-4).
+//   * K order (32-channel sub-chunk, tap column-major, channel) differs from conv_igemm's (64-channel chunk, tap, channel): same products, another
+//     summation order.  So this kernel is chosen by the CONFIGURATION (layer shape and map size), never by the batch: a layer it
+//     takes, it takes at every batch size, and a sample's bits stay independent of its batch.  The engine packs those layers'
+//     weights in this order (Loader::conv, `tall`).
+// Operand roles, bias-as-initial-accumulator and the register epilogue are conv_igemm's transposed-output path.
+#include <cstdio>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace hmv {
+
+typedef float tf32x16 __attribute__((ext_vector_type(16)));
+typedef float tf32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 tf16x8 __attribute__((ext_vector_type(8)));
+
+#define HMV_TGLDS16(gptr, lptr)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+constexpr int HT_HW = 34, HT_HROWS = 18 * 34;      // halo of a 16 x 32 block
+constexpr int HT_HP = 5;                           // halo DMA instructions per thread and image (612 pixels x 4 chunks / 512)
+constexpr int HT_IMG = HT_HP * 8192;               // bytes of a halo image slot
+constexpr int HT_WST = 8192;                       // bytes of a weight stage [128][32] halfs
+constexpr int HT_NWS = 8;                          // weight stages in LDS (a power of two); a stage is issued HT_NWS - 1 steps ahead
+constexpr int HT_LEAD = HT_NWS - 1;
+constexpr int HT_LDS = 2 * HT_IMG + HT_NWS * HT_WST;   // 147 456
+
+// DMAs issued after the weight stage of step s + 1 (issued first thing in step s + 1 - HT_LEAD) when step s waits for it: that
+// step's halo DMA (taps 0-4 carry one) and the weight and halo DMAs of the HT_LEAD - 1 steps since
+constexpr int ht_h(int tap) { return ((tap % 9) + 9) % 9 < HT_HP ? 1 : 0; }
+constexpr int ht_after_w(int tap) {
+    int n = HT_LEAD - 1;
+    for (int i = 0; i < HT_LEAD; ++i) n += ht_h(tap - i);
+    // the last step of a sub-chunk also needs the next halo image, whose last DMA went out on tap HT_HP - 1: 8 - (HT_HP - 1) weight
+    // DMAs have followed it
+    if (tap == 8 && n > 8 - (HT_HP - 1)) n = 8 - (HT_HP - 1);
+    return n;
+}
+static_assert(ht_after_w(2) < 60, "vmcnt is a 6-bit field");
+template <int TAP>
+__device__ __forceinline__ void ht_wait() {   // ... and this wave's fragment reads have left LDS (the slots they read are refilled next)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ht_after_w(TAP)) : "memory");
+}
+
+__global__ __launch_bounds__(512) void conv_ht_f16(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char tsm[];   // [2 halo images][4 weight stages]
+    char *wst = tsm + 2 * HT_IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    unsigned long long t_entry = 0, t0c = 0, t0r = 0, t1c = 0, t1r = 0;   // diagnostic stamps (hmv_bench_conv with HMV_BENCH_CLOCK)
+    if (p.dbg) t_entry = __builtin_amdgcn_s_memrealtime();
+
+    // ---- tile: the N-tiles of a pixel block are consecutive workgroups of one XCD (bijective XCD map as conv_igemm)
+    int blk, nt;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        blk = lid / p.ntiles;
+        nt = lid - blk * p.ntiles;
+    }
+    const int tyn = p.H >> 4, txn = p.W >> 5, per_img = tyn * txn;
+    const int n = blk / per_img, brem = blk - n * per_img, by = brem / txn, bx = brem - by * txn;
+    const _Float16 *zero16 = reinterpret_cast<const _Float16 *>(p.zero);
+    const int nchunk = p.Cin >> 5, nstep = 9 * nchunk;
+
+    // ---- DMA roles.  Halo: pass i moves 16-byte unit L = 512 i + tid = chunk L & 3 of halo pixel L >> 2 (the chunk it fetches is
+    // XOR-swizzled with (halo column >> 2) & 3: 64-byte rows, and a fragment read's 16 lanes are 16 consecutive columns of one row);
+    // out-of-image pixels and units past the halo come from the zero page.
+    const _Float16 *hsrc[HT_HP];
+#pragma unroll
+    for (int i = 0; i < HT_HP; ++i) {
+        const int L = 512 * i + tid, hp = L >> 2, hy = hp / HT_HW, hx = hp - hy * HT_HW;
+        const int iy = by * 16 - 1 + hy, ix = bx * 32 - 1 + hx;
+        const bool ok = hp < HT_HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        hsrc[i] = ok ? reinterpret_cast<const _Float16 *>(p.in) + ((size_t)(n * p.H + iy) * p.W + ix) * p.lda + 8 * ((L & 3) ^ ((hx >> 2) & 3)) : nullptr;
+    }
+    // weights: thread -> row tid >> 2 of the 128-row stage, physical chunk tid & 3 holding logical chunk (tid & 3) ^ ((row >> 2) & 3)
+    const _Float16 *wsrc = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(nt * 128 + (tid >> 2)) * p.ldw + 8 * ((tid & 3) ^ ((tid >> 4) & 3));
+
+    auto issue_w = [&](int s) {   // the weight stage of step s (past the end: a dummy from the zero page, nobody reads it)
+        const _Float16 *src = s < nstep ? wsrc + 32 * s : zero16;
+        asm volatile("" : "+v"(src));
+        HMV_TGLDS16(src, wst + (s & (HT_NWS - 1)) * HT_WST + wave * 1024);
+    };
+    auto issue_h = [&](int c, int i) {   // DMA i of the halo image of sub-chunk c (past the last: a dummy)
+        const _Float16 *src = (c < nchunk && hsrc[i]) ? hsrc[i] + 32 * c : zero16;
+        asm volatile("" : "+v"(src));
+        HMV_TGLDS16(src, tsm + (c & 1) * HT_IMG + i * 8192 + wave * 1024);
+    };
+
+    // ---- accumulators start at the bias
+    tf32x16 acc[4][2];
+    {
+        const float binit = 1.f / p.acc_scale;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float *bp = p.bias + nt * 128 + wn * 64 + 32 * b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const tf32x4 bq = *reinterpret_cast<const tf32x4 *>(bp + 16 * (q >> 1) + 8 * kh + 4 * (q & 1));
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[a][b][4 * q + u] = bq[u] * binit;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(acc[a][b]));   // the bias is in the accumulators BEFORE the first DMA is issued
+
+    // fragment addresses: pixel block a = image row 4 wm + a of the block, lane = column; weight block b = rows wn 64 + 32 b + swap23(l31)
+    const int wl31 = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int wrow = wn * 64 + wl31, wsw = (wrow >> 2) & 3;   // (+ 32 b leaves (row >> 2) & 3 unchanged)
+    // halo pixel of (block row a, column l31) at tap (dy, dx): (4 wm + a + dy) * 34 + l31 + dx; its swizzle depends on l31 + dx only,
+    // so the 3 x 2 byte offsets below plus compile-time displacements address every pixel fragment
+    int poff[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) poff[dx][j] = ((4 * wm) * HT_HW + l31) * 64 + ((2 * j + kh) ^ (((l31 + dx) >> 2) & 3)) * 16;
+    // The nine taps run column-major (dx, then dy): at one dx the pixel fragments of block row a at tap dy are halo row 4 wm + a + dy,
+    // so the three taps of a column share SIX halo rows -- four read at dy = 0, one more at each of dy = 1, 2 (12 fragment reads per
+    // wave and column instead of 24; with the four weight fragments of a step: 8 LDS reads per 16 MFMAs on average)
+    tf16x8 fr[6][2], fw[2][2];
+#define HT_ROW(s_, dx_, row_)                                                                               \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                        \
+        fr[row_][j_] = *reinterpret_cast<const tf16x8 *>(tsm + (((s_) / 9) & 1) * HT_IMG + poff[dx_][j_] + ((row_) * HT_HW + (dx_)) * 64);
+#define HT_READ(s_, tap_)                                                                                   \
+    {                                                                                                       \
+        const char *ws_ = wst + ((s_) & (HT_NWS - 1)) * HT_WST;                                                        \
+        _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                                    \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                \
+                fw[b_][j_] = *reinterpret_cast<const tf16x8 *>(ws_ + ((wrow + 32 * b_) * 4 + ((2 * j_ + kh) ^ wsw)) * 16); \
+        if ((tap_) % 3 == 0) { HT_ROW(s_, (tap_) / 3, 0) HT_ROW(s_, (tap_) / 3, 1) HT_ROW(s_, (tap_) / 3, 2) HT_ROW(s_, (tap_) / 3, 3) }   \
+        else if ((tap_) % 3 == 1) { HT_ROW(s_, (tap_) / 3, 4) }                                             \
+        else { HT_ROW(s_, (tap_) / 3, 5) }                                                                  \
+    }
+#define HT_MFMA(tap_)                                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                        \
+        _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                                    \
+            _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                                \
+                acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[b_][j_], fr[a_ + (tap_) % 3][j_], acc[a_][b_], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+#define HT_BAR()                                                                                            \
+    asm volatile("s_barrier" ::: "memory");                                                                 \
+    __builtin_amdgcn_sched_barrier(0)
+
+    // ---- prologue: the halo of sub-chunk 0, then HT_LEAD "steps before the first" that issue what those steps would have issued --
+    // the weight stages of steps 0 .. HT_LEAD - 1 and, on the taps that carry one, a dummy halo DMA (zero page into image 1, which
+    // the real halo of sub-chunk 1 overwrites later: same wave, same addresses, in order) -- so the loop's static counts hold from step 0
+#pragma unroll
+    for (int i = 0; i < HT_HP; ++i) issue_h(0, i);
+#pragma unroll
+    for (int f = -HT_LEAD; f < 0; ++f) {
+        issue_w(f + HT_LEAD);
+        if (ht_h(f)) {
+            const _Float16 *src = zero16;
+            asm volatile("" : "+v"(src));
+            HMV_TGLDS16(src, tsm + HT_IMG + wave * 1024);
+        }
+    }
+    ht_wait<8>();   // as step -1 would: stage 0 (and the halo before it) has landed
+    HT_BAR();
+    if (p.dbg) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+    if (wm >= 2) { HT_BAR(); }   // the second wave half runs one barrier behind the first from here on
+
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int s = 9 * c + tap;
+            HT_READ(s, tap);
+            issue_w(s + HT_LEAD);
+            if (tap < HT_HP) issue_h(c + 1, tap);
+            // the weight stage of step s + 1 (read in the next phase) has landed; with it every older halo DMA
+            switch (tap) {
+                case 0: ht_wait<0>(); break; case 1: ht_wait<1>(); break; case 2: ht_wait<2>(); break;
+                case 3: ht_wait<3>(); break; case 4: ht_wait<4>(); break; case 5: ht_wait<5>(); break;
+                case 6: ht_wait<6>(); break; case 7: ht_wait<7>(); break; default: ht_wait<8>(); break;
+            }
+            HT_BAR();
+            HT_MFMA(tap);
+            __builtin_amdgcn_sched_barrier(0);
+            HT_BAR();
+        }
+    }
+    if (wm < 2) { HT_BAR(); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.dbg) { t1c = __builtin_amdgcn_s_memtime(); t1r = __builtin_amdgcn_s_memrealtime(); }
+#undef HT_READ
+#undef HT_ROW
+#undef HT_MFMA
+#undef HT_BAR
+
+    // ---- epilogue straight from the accumulators: register 8j + u of block (a, b) = channel 32 b + 16 j + 8 kh + u of pixel (row a, column l31)
+    const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    const int nb0 = nt * 128 + wn * 64;
+    const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 7) & ~7);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const size_t pix = (size_t)(n * p.H + by * 16 + 4 * wm + a) * p.W + bx * 32 + l31;
+        _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + pix * p.ldc;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = nb0 + 32 * b + 16 * j + 8 * kh;
+                tf16x8 hv;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + 0.f, lo);
+                if (col < cend) *reinterpret_cast<tf16x8 *>(orow + col) = hv;
+            }
+    }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *d = p.dbg + 8 * (size_t)blockIdx.x;
+        d[0] = t1c - t0c; d[1] = t1r - t0r; d[2] = t_entry; d[3] = t0r; d[4] = t1r; d[5] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// ====================================================================== host side
+// shape rule (the engine asks it at weight-packing time and at launch: the same answer for every batch)
+bool conv_ht_shape_ok(int R, int S, int stride, int pad, int Cin, int Cout, int H, int W) {
+    static int off = -1;   // development knob: HMV_NO_HT=1 keeps these layers on conv_igemm's 256 x 256 halo tiles (A/B runs)
+    if (off < 0) off = getenv("HMV_NO_HT") ? 1 : 0;
+    return !off && R == 3 && S == 3 && stride == 1 && pad == 1 && Cin % 32 == 0 && Cin >= 64 && Cout % 128 == 0 && H % 16 == 0 && W % 32 == 0 &&
+           H > 0 && W > 0;
+}
+
+hipError_t launch_conv_ht(ConvParams p, hipStream_t s, const char **name) {
+    if (!p.in_f16 || !p.out_f16 || p.res || !conv_ht_shape_ok(p.R, p.S, p.stride, p.pad_h, p.Cin, p.Cout, p.H, p.W) || p.pad_w != 1 || p.Ho != p.H ||
+        p.Wo != p.W || p.up || p.in2 || p.ksl > 1 || p.phases > 1 || p.cwrap || p.x3_plane || p.out_split || p.acc_shift || p.rd_cout ||
+        p.scatter || p.rg_out || (p.act != ACT_NONE && p.act != ACT_RELU) || (p.lda & 7) || p.lda < p.Cin || (p.ldw & 7) || (p.ldc & 7) || p.Kpad < 9 * p.Cin)
+        return hipErrorInvalidValue;
+    static bool configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!configured[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_ht_f16), hipFuncAttributeMaxDynamicSharedMemorySize, HT_LDS);
+        if (e != hipSuccess) return e;
+        configured[dev] = true;
+    }
+    p.mtiles = p.N * (p.H >> 4) * (p.W >> 5);
+    p.ntiles = p.Cout / 128;
+    if (name) *name = "conv_ht_f16<512x128,3x3>";
+    hipLaunchKernelGGL(conv_ht_f16, dim3(p.mtiles * p.ntiles), dim3(512), HT_LDS, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace hmv

@@ -1327,6 +1327,8 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     if (p.phases > 1 && (p.phases != 4 || !p.scatter || p.R != 2 || p.S != 2 || p.stride != 1 || p.ksl > 1 || p.in2 || p.rd_cout || p.phase_stride == 0))
         return hipErrorInvalidValue;   // the merged launch exists for the four 2x2 phases of the k4 s2 p1 transposed conv only
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
+    // weights packed for the tall-tile 3x3 kernel: that kernel at every batch size (another K order is another rounding)
+    if (p.tall) return generic ? hipErrorInvalidValue : launch_conv_ht(p, s, name);
     // short-reduction residual 1x1 convs over many pixels (fp16 Bottleneck conv3): the persistent weight-stationary kernel
     if (!generic && conv_stream_supported(p)) return launch_conv_stream(p, s, name);
     // MFMA-heavy fp16 1x1 convs without a residual on 256 x 256 tiles: the counted-vmcnt, phase-interleaved main loop

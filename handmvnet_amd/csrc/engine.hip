@@ -51,6 +51,7 @@ struct Layer {
     int plane = 0;      // HMV_F32X3 (split operands): physical channels per (hi | lo) plane; Cin is then the virtual 3 * plane
     int rd_cout = 0;    // row-decomposed 3x3 (conv_igemm.hip, RD): the real Cout; Cout / R / S then describe the 3x1 GEMM
     bool f16 = false;   // operands (activations + packed weights) are fp16; bias stays fp32
+    bool tall = false;  // fp16 3x3 packed in conv_ht.hip's K order (32-channel sub-chunk, s, r, c % 32): runs on that kernel at every batch
     std::string label;
 };
 
@@ -353,7 +354,7 @@ struct Loader {
     // nn.Conv2d weight OIHW (+ optional bias key) followed by an optional BN
     // (wsrc: an already re-arranged OIHW weight instead of the state_dict tensor `wkey` -- the space-to-depth stem)
     void conv(Layer &L, const std::string &label, const std::string &wkey, const std::string &bkey, const std::string &bn,
-              int Cout, int Cin, int R, int S, int cin_pad = 0, bool f16 = false, bool rd = false, const float *wsrc = nullptr) {
+              int Cout, int Cin, int R, int S, int cin_pad = 0, bool f16 = false, bool rd = false, const float *wsrc = nullptr, bool tall = false) {
         const HostTensor *w = wsrc ? nullptr : get(wkey, {Cout, Cin, R, S});
         const HostTensor *cb = bkey.empty() ? nullptr : get(bkey, {Cout});
         std::vector<double> sc, sh;
@@ -367,9 +368,10 @@ struct Loader {
         const int cp = sp ? (x3n ? 2 * plane : 3 * plane) : plane;   // the channel count the kernel's K order walks
         const float *wd = wsrc ? wsrc : w->data.data();
         const bool chunked = cp % (f16 ? 64 : 32) == 0 && (!sp || (x3n && plane % 32 == 0) || (!x3n && plane % 64 == 0));
+        tall = tall && f16 && !sp && !cin_pad && !rd && !wsrc;
         auto wt = [=](int o, int k) -> float {
             int c, tap;
-            const int CH = f16 ? 64 : 32;
+            const int CH = (f16 && !tall) ? 64 : 32;
             if (x3n && chunked) {
                 const int step = k / 64, c32 = k % 32;
                 tap = step % (R * S);
@@ -382,6 +384,7 @@ struct Loader {
             } else if (chunked) {   // K order (chunk, r, s, c % CH), CH = 32 (fp32) / 64 (fp16): conv_igemm.hip
                 const int chunk = k / (CH * R * S), rem = k % (CH * R * S);
                 tap = rem / CH;
+                if (tall) tap = (tap % 3) * 3 + tap / 3;   // conv_ht.hip walks the taps column-major: (sub-chunk, s, r, c % 32)
                 c = chunk * CH + rem % CH;
             } else {          // dense K order (r, s, c) over the real channels: the stem, HRNet's 40 / 80-channel tensors
                 c = k % cp;
@@ -435,6 +438,7 @@ struct Loader {
         finish(L, label, cp, Cout, R, S, Kpack, wt, has_bn ? &sc : nullptr, has_bn ? &sh : nullptr,
                cb ? cb->data.data() : nullptr, f16, sp ? &lo_plane : nullptr);
         L.Kreal = R * S * Cin;
+        L.tall = tall;
         if (sp) { L.plane = plane; L.x3n = x3n; }
     }
 
@@ -682,7 +686,12 @@ int hmv_finalize_weights(hmv_handle h) {
             const int outc = planes * exp;
             if (h->paper) {
                 L.conv(b.c1, lab + ".conv1", p + ".conv1.weight", "", p + ".bn1", planes, inpl, 1, 1, 0, h16);
-                L.conv(b.c2, lab + ".conv2", p + ".conv2.weight", "", p + ".bn2", planes, planes, 3, 3, 0, h16);
+                // conv2 at stride 1 on a map that tiles into 16 x 32 blocks: the tall-tile kernel (conv_ht.hip), chosen by the
+                // configuration alone -- the map is H/8 x W/8 from layer2.1 on (layer3 keeps it: the paper variant's stride 1)
+                auto hup = [](int n) { return (n - 1) / 2 + 1; };
+                const int mh = hup(hup(hup(c.height))), mw = hup(hup(hup(c.width)));
+                const bool tall = h16 && li >= 1 && b.stride == 1 && conv_ht_shape_ok(3, 3, 1, 1, planes, planes, mh, mw);
+                L.conv(b.c2, lab + ".conv2", p + ".conv2.weight", "", p + ".bn2", planes, planes, 3, 3, 0, h16, false, nullptr, tall);
                 L.conv(b.c3, lab + ".conv3", p + ".conv3.weight", "", p + ".bn3", outc, planes, 1, 1, 0, h16);
             } else {
                 L.conv(b.c1, lab + ".conv1", p + ".conv1.weight", "", p + ".bn1", planes, inpl, 3, 3, 0, h16);
@@ -976,6 +985,7 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
         p.R = R; p.S = S; p.stride = stride; p.pad_h = pad; p.pad_w = pad; p.K = K; p.Kpad = Kpad;
         p.M = N * Ho * Wo; p.ldc = Cout; p.ldr = Cout; p.act = ACT_RELU; p.osy = p.osx = 1;
         p.lda = lda; p.ldw = ldw;
+        p.tall = getenv("HMV_BENCH_TALL") != nullptr;   // the tall-tile 3x3 kernel (conv_ht.hip); random weights have no order
         unsigned long long *ddbg = nullptr;
         const int nblk_dbg = ((p.M + 63) / 64) * ((Cout + 31) / 32);
         if (getenv("HMV_BENCH_CLOCK")) {
@@ -1082,6 +1092,7 @@ struct Runner {
         p.rg_out = rg_out; p.rg_in = rg_in;
         p.scatter = scatter; p.osy = scatter ? 2 : 1; p.osx = scatter ? 2 : 1; p.ooy = ooy; p.oox = oox;
         p.up = up; p.fill = fill ? 1 : 0;
+        p.tall = L.tall;
         if (L.rd_cout) { p.rd_cout = L.rd_cout; p.pad_w = 0; }   // L.R x L.S is the 3x1 GEMM, the epilogue sums the s groups
         if (L.plane) {   // HMV_F32X3: [hi | lo] rows in, pairs out (unless this layer writes fp32), pairs as residual
             p.lda = 2 * L.plane;
@@ -2044,7 +2055,12 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
 // out16: the layer writes fp16 rows (plain fp16 mode only), as every backbone layer of the fp16 path does
 static int op_conv2d_any(const char *who, int32_t device, int32_t dtype, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
                          const float *w_oihw, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
-                         int32_t pad, const float *residual, int32_t relu, void *out, bool out16, const char **kernel_name, void *stream) {
+                         int32_t pad, const float *residual, int32_t relu, void *out, bool out16, const char **kernel_name, void *stream,
+                         bool tall = false) {
+    if (tall && (residual || !out16 || !conv_ht_shape_ok(R, S, stride, pad, Cin, Cout, H, W))) {
+        g_create_err = std::string(who) + ": the tall-tile kernel takes 3x3 stride-1 pad-1 convs without residual, Cin % 32 == 0 (>= 64), Cout % 128 == 0, H % 16 == 0, W % 32 == 0";
+        return HMV_ERR_ARG;
+    }
     if ((dtype != HMV_F16 && dtype != HMV_F32X3) || !in || !w_oihw || !out || Cin % 8 != 0 || Cout % 4 != 0 || (out16 && dtype != HMV_F16)) {
         g_create_err = std::string(who) + ": dtype must be HMV_F32 / HMV_F16 / HMV_F32X3; the fp16-based modes need Cin % 8 == 0, Cout % 4 == 0";
         return HMV_ERR_ARG;
@@ -2066,7 +2082,7 @@ static int op_conv2d_any(const char *who, int32_t device, int32_t dtype, const f
     Loader L{&eng};
     L.split = dtype == HMV_F32X3;
     Layer layer;
-    L.conv(layer, "op", "w", bias_host ? "b" : "", "", Cout, Cin, R, S, 0, true);
+    L.conv(layer, "op", "w", bias_host ? "b" : "", "", Cout, Cin, R, S, 0, true, false, nullptr, tall);
     int rc = L.rc;
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     const size_t rows_in = (size_t)N * H * W, rows_out = (size_t)N * Ho * Wo;
@@ -2109,12 +2125,13 @@ extern "C" int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int
                                  const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad,
                                  const float *residual, int32_t relu, void *out_f16, int32_t kernel_sel, const char **kernel_name,
                                  void *stream) {
-    if (kernel_sel < 0 || kernel_sel > 2) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0, 1 or 2"; return HMV_ERR_ARG; }
-    conv_stream_set_mode(kernel_sel == 0 ? -1 : kernel_sel - 1);
-    conv_gemm8_set_mode(kernel_sel == 0 ? -1 : kernel_sel - 1);
-    conv_hs_set_mode(kernel_sel == 0 ? -1 : kernel_sel - 1);
+    if (kernel_sel < 0 || kernel_sel > 3) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0, 1, 2 or 3"; return HMV_ERR_ARG; }
+    const int force = kernel_sel == 0 ? -1 : (kernel_sel == 2 ? 1 : 0);   // 3 (tall-tile packing) keeps the other special kernels out
+    conv_stream_set_mode(force);
+    conv_gemm8_set_mode(force);
+    conv_hs_set_mode(force);
     const int rc = op_conv2d_any("hmv_op_conv2d_f16", device, HMV_F16, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad,
-                                 residual, relu, out_f16, true, kernel_name, stream);
+                                 residual, relu, out_f16, true, kernel_name, stream, kernel_sel == 3);
     conv_stream_set_mode(-1);
     conv_gemm8_set_mode(-1);
     conv_hs_set_mode(-1);

@@ -46,6 +46,7 @@ struct ConvParams {
     int acc_shift;      // split layers: the packed weights are W * 2^acc_shift (keeps W_lo out of the fp16 subnormals);
     float acc_scale;    //   the epilogue multiplies the accumulator by 2^-acc_shift (filled in by launch_conv)
     int out_split;      // write (hi, lo) pairs (plane stride ldc / 2) instead of one fp16 value
+    int tall;           // fp16 3x3 whose weights are packed in conv_ht.hip's K order: that kernel or an error, at every batch size
     int rd_cout;        // row-decomposed 3x3 (narrow Cout): the real channel count; Cout is then 3 * rd_cout, R = 3, S = 1
     // second A source of a plain 1x1 conv (Bottleneck conv3 and its block's downsample conv as ONE GEMM over the concatenated
     // reduction [t2 | x] . [W3 ; Wds], resnet.py:124-144): reduction indices >= ksplit read `in2`, an NHWC tensor
@@ -154,6 +155,10 @@ hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name);
 bool conv_hs_supported(const ConvParams &p);
 void conv_hs_set_mode(int mode);
 hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name);
+// conv_ht.hip: fp16 3x3 stride-1 convs on tall 512-pixel x 128-channel tiles (K order (32-channel sub-chunk, r, s, c % 32)); the
+// shape rule is asked at weight-packing time, so a layer it takes runs there at every batch size
+bool conv_ht_shape_ok(int R, int S, int stride, int pad, int Cin, int Cout, int H, int W);
+hipError_t launch_conv_ht(ConvParams p, hipStream_t s, const char **name);
 
 // ---- fusion_kernels.hip: the launch-bound tail as fused kernels
 // Everything of a fusion block behind its to_out GEMM (layers.py:224-233 / 161-174; learnable-query blocks: layers.py:293-299):

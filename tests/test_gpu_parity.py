@@ -323,6 +323,48 @@ def test_stream_kernel_is_bit_identical(shape):
         assert err < 1e-3, err
 
 
+# 3x3 convs on the tall 512-pixel x 128-channel tiles (conv_ht.hip): 1 to 6 blocks per image, one and several N-tiles, 2 to 8
+# sub-chunks, ReLU on and off, more tiles than CUs
+HT_SHAPES = [(2, 16, 32, 64, 128, 3, 1, 1, False, True), (1, 32, 32, 128, 128, 3, 1, 1, False, False), (3, 48, 64, 256, 256, 3, 1, 1, False, True),
+             (5, 32, 32, 256, 384, 3, 1, 1, False, True), (72, 32, 32, 128, 256, 3, 1, 1, False, True)]
+
+
+@pytest.mark.parametrize("shape", HT_SHAPES)
+def test_tall_tile_kernel(shape):
+    """conv_ht.hip sums the same products as conv_igemm in another order (32-channel sub-chunks), so the two agree to fp32
+    accumulation noise under the fp16 output rounding, not bit for bit -- which is why the engine chooses it by the layer's shape and
+    map size alone, never by the batch.  Checked: against conv_igemm (at most the last fp16 bit, rarely), against torch fp64 at fp16
+    accuracy, and image 0 alone == image 0 inside the batch, bit for bit."""
+    a, ka, (x, w, b, res, relu) = _run_conv_f16(shape, 3)
+    c, kc, _ = _run_conv_f16(shape, 1)
+    assert ka.startswith("conv_ht_f16") and kc.startswith("conv_igemm_f16"), (ka, kc)
+    assert torch.isfinite(a.float()).all()
+    d = (a.float() - c.float()).abs()
+    scale = c.float().abs().max().item()
+    assert d.max().item() <= 2e-3 * scale, (d.max().item(), scale)           # one fp16 ulp near the largest value
+    assert (d > 0).float().mean().item() < 0.02                              # and only where the fp32 sums straddle a rounding boundary
+    if shape[0] * shape[1] * shape[2] <= 8192:
+        xh, wh = x.half().double(), w.half().double()
+        ref = torch.nn.functional.conv2d(xh.permute(0, 3, 1, 2), wh, b.double(), stride=1, padding=1).permute(0, 2, 3, 1)
+        if relu:
+            ref = ref.clamp_min(0)
+        err = (a.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-3, err
+    if shape[0] > 1:
+        one = (1,) + shape[1:]
+        # same seed stream: _run_conv_f16 seeds by the shape, so rebuild image 0 from the batch's own tensors
+        from handmvnet_amd import _lib
+        lib = _lib.load()
+        dev = torch.device("cuda:0")
+        x0 = x[:1].contiguous().to(dev)
+        out = torch.full((1,) + tuple(a.shape[1:]), float("nan"), device=dev, dtype=torch.float16)
+        wc, bc = w.contiguous().numpy(), b.contiguous().numpy()
+        rc = lib.hmv_op_conv2d_f16(0, x0.data_ptr(), 1, one[1], one[2], one[3], wc.ctypes.data_as(ctypes.c_void_p),
+                                   bc.ctypes.data_as(ctypes.c_void_p), one[4], 3, 3, 1, 1, None, int(relu), out.data_ptr(), 3, None, None)
+        assert rc == 0, lib.hmv_last_error(None)
+        assert torch.equal(out.cpu()[0].view(torch.int16), a[0].view(torch.int16))
+
+
 def _random_conv_shapes(n, seed):
     rng = np.random.default_rng(seed)
     shapes = []

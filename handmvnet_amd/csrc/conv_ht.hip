@@ -16,7 +16,7 @@
 //   * main loop: conv_gemm8's structure with one phase per k-step {fragment reads . DMA . counted `s_waitcnt vmcnt(N)` . barrier .
 //     16 MFMAs . barrier}, the two wave halves one barrier apart, raw barriers, nothing drained inside the loop.  N is static per
 //     tap: the instructions issued after the weight stage that must have landed (one weight DMA per step, one halo DMA on taps 0-4).
-//   * K order (32-channel sub-chunk, tap column-major, channel) differs from conv_igemm's (64-channel chunk, tap, channel): same products, another
+//   * K order (32-channel sub-chunk, tap, channel) differs from conv_igemm's (64-channel chunk, tap, channel): same products, another
 //     summation order.  So this kernel is chosen by the CONFIGURATION (layer shape and map size), never by the batch: a layer it
 //     takes, it takes at every batch size, and a sample's bits stay independent of its batch.  The engine packs those layers'
 //     weights in this order (Loader::conv, `tall`).
@@ -143,29 +143,24 @@ __global__ __launch_bounds__(512) void conv_ht_f16(const ConvParams p) {
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int j = 0; j < 2; ++j) poff[dx][j] = ((4 * wm) * HT_HW + l31) * 64 + ((2 * j + kh) ^ (((l31 + dx) >> 2) & 3)) * 16;
-    // The nine taps run column-major (dx, then dy): at one dx the pixel fragments of block row a at tap dy are halo row 4 wm + a + dy,
-    // so the three taps of a column share SIX halo rows -- four read at dy = 0, one more at each of dy = 1, 2 (12 fragment reads per
-    // wave and column instead of 24; with the four weight fragments of a step: 8 LDS reads per 16 MFMAs on average)
-    tf16x8 fr[6][2], fw[2][2];
-#define HT_ROW(s_, dx_, row_)                                                                               \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                        \
-        fr[row_][j_] = *reinterpret_cast<const tf16x8 *>(tsm + (((s_) / 9) & 1) * HT_IMG + poff[dx_][j_] + ((row_) * HT_HW + (dx_)) * 64);
+    tf16x8 fp[4][2], fw[2][2];
 #define HT_READ(s_, tap_)                                                                                   \
     {                                                                                                       \
-        const char *ws_ = wst + ((s_) & (HT_NWS - 1)) * HT_WST;                                                        \
+        const char *img_ = tsm + (((s_) / 9) & 1) * HT_IMG;                                                 \
+        const char *ws_ = wst + ((s_) & (HT_NWS - 1)) * HT_WST;                                             \
         _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                                    \
             _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                \
                 fw[b_][j_] = *reinterpret_cast<const tf16x8 *>(ws_ + ((wrow + 32 * b_) * 4 + ((2 * j_ + kh) ^ wsw)) * 16); \
-        if ((tap_) % 3 == 0) { HT_ROW(s_, (tap_) / 3, 0) HT_ROW(s_, (tap_) / 3, 1) HT_ROW(s_, (tap_) / 3, 2) HT_ROW(s_, (tap_) / 3, 3) }   \
-        else if ((tap_) % 3 == 1) { HT_ROW(s_, (tap_) / 3, 4) }                                             \
-        else { HT_ROW(s_, (tap_) / 3, 5) }                                                                  \
+        _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                                    \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                \
+                fp[a_][j_] = *reinterpret_cast<const tf16x8 *>(img_ + poff[(tap_) % 3][j_] + ((a_ + (tap_) / 3) * HT_HW + (tap_) % 3) * 64); \
     }
-#define HT_MFMA(tap_)                                                                                       \
+#define HT_MFMA()                                                                                           \
     __builtin_amdgcn_s_setprio(1);                                                                          \
     _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                        \
         _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                                    \
             _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                                \
-                acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[b_][j_], fr[a_ + (tap_) % 3][j_], acc[a_][b_], 0, 0, 0); \
+                acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[b_][j_], fp[a_][j_], acc[a_][b_], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);
 #define HT_BAR()                                                                                            \
     asm volatile("s_barrier" ::: "memory");                                                                 \
@@ -204,7 +199,7 @@ __global__ __launch_bounds__(512) void conv_ht_f16(const ConvParams p) {
                 case 6: ht_wait<6>(); break; case 7: ht_wait<7>(); break; default: ht_wait<8>(); break;
             }
             HT_BAR();
-            HT_MFMA(tap);
+            HT_MFMA();
             __builtin_amdgcn_sched_barrier(0);
             HT_BAR();
         }
@@ -213,7 +208,6 @@ __global__ __launch_bounds__(512) void conv_ht_f16(const ConvParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (p.dbg) { t1c = __builtin_amdgcn_s_memtime(); t1r = __builtin_amdgcn_s_memrealtime(); }
 #undef HT_READ
-#undef HT_ROW
 #undef HT_MFMA
 #undef HT_BAR
 
@@ -244,6 +238,10 @@ __global__ __launch_bounds__(512) void conv_ht_f16(const ConvParams p) {
 }
 
 // ====================================================================== host side
+static int g_ht_mode = -1;   // -1: launch_conv's rule (enough tiles to fill the chip); 0 never, 1 always (op-level tests)
+void conv_ht_set_mode(int mode) { g_ht_mode = mode; }
+int conv_ht_mode() { return g_ht_mode; }
+
 // shape rule (the engine asks it at weight-packing time and at launch: the same answer for every batch)
 bool conv_ht_shape_ok(int R, int S, int stride, int pad, int Cin, int Cout, int H, int W) {
     static int off = -1;   // development knob: HMV_NO_HT=1 keeps these layers on conv_igemm's 256 x 256 halo tiles (A/B runs)

@@ -161,11 +161,14 @@ constexpr int lds_floats(int BM, int BN, int WGM, int KB, bool full = false, boo
 constexpr int min_waves(int BM, int BN, int NT, bool f16, bool generic, bool rd, int KB) {
     return (HMV_OCC2 && KB == (f16 ? 32 : 16) && !generic && !rd && NT == 512 && BM * BN == 256 * 128) ? 4 : (NT == 512 ? 2 : 1);
 }
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false, bool X3 = false>
+// C32 (fp16, MODE_TAPS, KB = 32): the packed K order walks 32-channel chunks -- conv_ht.hip's order, so that the layers packed for
+// the tall-tile kernel run here, with the same bits, when the batch is too small to fill the chip with 512-pixel tiles
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false, bool X3 = false, bool C32 = false>
 __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, sizeof(T) == 2, GENERIC, RD, KB)) void conv_igemm(const ConvParams p) {
     constexpr bool F16 = sizeof(T) == 2;
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
-    constexpr int CH = F16 ? 64 : 32;    // channel-chunk width of the packed K order
+    constexpr int CH = (F16 && !C32) ? 64 : 32;    // channel-chunk width of the packed K order
+    static_assert(!C32 || (F16 && KB == 32 && MODE == MODE_TAPS && !GENERIC && !PARTN && !RD && !X3), "32-channel chunk order");
     constexpr int KB4 = KB * (int)sizeof(T) / 4;   // k-step in 4-byte units (row bytes / 4)
     constexpr int NT = 64 * WGM * WGN;   // 4 or 8 waves
     constexpr int LPR = KB / EPC;        // lanes (16-byte chunks) per tile row: 8 (128-byte rows) or 4 (64-byte rows)
@@ -1252,7 +1255,7 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
     return TILE_128x32;
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false, bool X3 = false>
+template <typename T, int BM, int BN, int WGM, int WGN, int MODE, bool GENERIC, int KB, bool PARTN = false, bool RD = false, bool X3 = false, bool C32 = false>
 static hipError_t launch_one(ConvParams p, hipStream_t s) {
     if constexpr (!X3 && sizeof(T) == 2 && KB == 64 && !GENERIC && !PARTN && !RD && MODE != MODE_HALO) {
         if (p.x3_plane) return launch_one<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD, true>(p, s);
@@ -1262,7 +1265,7 @@ static hipError_t launch_one(ConvParams p, hipStream_t s) {
     constexpr int ns = ring_stages(sizeof(T) == 2, KB, GENERIC, RD, BM, BN);
     const size_t lds = MODE == MODE_HALO ? (size_t)2 * (HALO_ROWS + BN) * KB * sizeof(T) + 256   // two halo images + two weight stages
                                          : (size_t)lds_floats(BM, BN, WGM, KB * (int)sizeof(T) / 4, RD, !tout, ns) * sizeof(float) + (tout ? 256 : 0);
-    auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD, X3>;
+    auto kern = conv_igemm<T, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD, X3, C32>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
@@ -1327,8 +1330,24 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     if (p.phases > 1 && (p.phases != 4 || !p.scatter || p.R != 2 || p.S != 2 || p.stride != 1 || p.ksl > 1 || p.in2 || p.rd_cout || p.phase_stride == 0))
         return hipErrorInvalidValue;   // the merged launch exists for the four 2x2 phases of the k4 s2 p1 transposed conv only
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
-    // weights packed for the tall-tile 3x3 kernel: that kernel at every batch size (another K order is another rounding)
-    if (p.tall) return generic ? hipErrorInvalidValue : launch_conv_ht(p, s, name);
+    // weights packed for the tall-tile 3x3 kernel (conv_ht.hip; K order (32-channel chunk, r, s, c % 32)): that kernel when its 512-pixel x
+    // 128-channel tiles fill the chip, else the 64 x 64 / 128 x 128 tiles of this file walking the SAME order -- same operand roles,
+    // same accumulation sequence, same epilogue arithmetic, so the bits do not depend on which of the two ran (tests/test_gpu_parity.py)
+    if (p.tall) {
+        if (generic || !conv_ht_shape_ok(p.R, p.S, p.stride, p.pad_h, p.Cin, p.Cout, p.H, p.W) || !p.in_f16 || !p.out_f16 || p.res || p.in2 ||
+            p.x3_plane || p.cwrap || p.rd_cout || p.ksl > 1 || p.phases > 1 || p.up)
+            return hipErrorInvalidValue;
+        static int ht_min = -1;   // development knob: HMV_HT_MIN_TILES=<n> (default 256: one tile per CU)
+        if (ht_min < 0) { const char *e = getenv("HMV_HT_MIN_TILES"); ht_min = e ? atoi(e) : 256; }
+        const long long ht_tiles = (long long)p.N * (p.H >> 4) * (p.W >> 5) * (p.Cout / 128);
+        if (conv_ht_mode() > 0 || (conv_ht_mode() < 0 && ht_tiles >= ht_min)) return launch_conv_ht(p, s, name);
+        if ((long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) < 256) {
+            if (name) *name = "conv_igemm_f16<64x64,taps,c32>";
+            return launch_one<_Float16, 64, 64, 2, 2, MODE_TAPS, false, 32, false, false, false, true>(p, s);
+        }
+        if (name) *name = "conv_igemm_f16<128x128,taps,c32>";
+        return launch_one<_Float16, 128, 128, 2, 2, MODE_TAPS, false, 32, false, false, false, true>(p, s);
+    }
     // short-reduction residual 1x1 convs over many pixels (fp16 Bottleneck conv3): the persistent weight-stationary kernel
     if (!generic && conv_stream_supported(p)) return launch_conv_stream(p, s, name);
     // MFMA-heavy fp16 1x1 convs without a residual on 256 x 256 tiles: the counted-vmcnt, phase-interleaved main loop

@@ -51,7 +51,7 @@ struct Layer {
     int plane = 0;      // HMV_F32X3 (split operands): physical channels per (hi | lo) plane; Cin is then the virtual 3 * plane
     int rd_cout = 0;    // row-decomposed 3x3 (conv_igemm.hip, RD): the real Cout; Cout / R / S then describe the 3x1 GEMM
     bool f16 = false;   // operands (activations + packed weights) are fp16; bias stays fp32
-    bool tall = false;  // fp16 3x3 packed in conv_ht.hip's K order (32-channel sub-chunk, s, r, c % 32): runs on that kernel at every batch
+    bool tall = false;  // fp16 3x3 packed in conv_ht.hip's K order (32-channel chunk, r, s, c % 32): runs on that kernel at every batch
     std::string label;
 };
 
@@ -384,7 +384,6 @@ struct Loader {
             } else if (chunked) {   // K order (chunk, r, s, c % CH), CH = 32 (fp32) / 64 (fp16): conv_igemm.hip
                 const int chunk = k / (CH * R * S), rem = k % (CH * R * S);
                 tap = rem / CH;
-                if (tall) tap = (tap % 3) * 3 + tap / 3;   // conv_ht.hip walks the taps column-major: (sub-chunk, s, r, c % 32)
                 c = chunk * CH + rem % CH;
             } else {          // dense K order (r, s, c) over the real channels: the stem, HRNet's 40 / 80-channel tensors
                 c = k % cp;
@@ -2125,13 +2124,15 @@ extern "C" int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int
                                  const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad,
                                  const float *residual, int32_t relu, void *out_f16, int32_t kernel_sel, const char **kernel_name,
                                  void *stream) {
-    if (kernel_sel < 0 || kernel_sel > 3) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0, 1, 2 or 3"; return HMV_ERR_ARG; }
-    const int force = kernel_sel == 0 ? -1 : (kernel_sel == 2 ? 1 : 0);   // 3 (tall-tile packing) keeps the other special kernels out
+    if (kernel_sel < 0 || kernel_sel > 4) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0 .. 4"; return HMV_ERR_ARG; }
+    const int force = kernel_sel == 0 ? -1 : (kernel_sel == 2 ? 1 : 0);   // 3 / 4 (tall-tile packing) keep the other special kernels out
+    conv_ht_set_mode(kernel_sel == 3 ? 1 : (kernel_sel == 4 ? 0 : -1));
     conv_stream_set_mode(force);
     conv_gemm8_set_mode(force);
     conv_hs_set_mode(force);
     const int rc = op_conv2d_any("hmv_op_conv2d_f16", device, HMV_F16, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad,
-                                 residual, relu, out_f16, true, kernel_name, stream, kernel_sel == 3);
+                                 residual, relu, out_f16, true, kernel_name, stream, kernel_sel >= 3);
+    conv_ht_set_mode(-1);
     conv_stream_set_mode(-1);
     conv_gemm8_set_mode(-1);
     conv_hs_set_mode(-1);

@@ -155,10 +155,12 @@ hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name);
 bool conv_hs_supported(const ConvParams &p);
 void conv_hs_set_mode(int mode);
 hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name);
-// conv_ht.hip: fp16 3x3 stride-1 convs on tall 512-pixel x 128-channel tiles (K order (32-channel sub-chunk, r, s, c % 32)); the
+// conv_ht.hip: fp16 3x3 stride-1 convs on tall 512-pixel x 128-channel tiles (K order (32-channel chunk, r, s, c % 32)); the
 // shape rule is asked at weight-packing time, so a layer it takes runs there at every batch size
 bool conv_ht_shape_ok(int R, int S, int stride, int pad, int Cin, int Cout, int H, int W);
 hipError_t launch_conv_ht(ConvParams p, hipStream_t s, const char **name);
+void conv_ht_set_mode(int mode);   // -1 launch_conv's rule, 0 never (the c32 tiles of conv_igemm.hip), 1 always: op-level tests
+int conv_ht_mode();
 
 // ---- fusion_kernels.hip: the launch-bound tail as fused kernels
 // Everything of a fusion block behind its to_out GEMM (layers.py:224-233 / 161-174; learnable-query blocks: layers.py:293-299):

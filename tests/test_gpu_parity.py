@@ -331,13 +331,18 @@ HT_SHAPES = [(2, 16, 32, 64, 128, 3, 1, 1, False, True), (1, 32, 32, 128, 128, 3
 
 @pytest.mark.parametrize("shape", HT_SHAPES)
 def test_tall_tile_kernel(shape):
-    """conv_ht.hip sums the same products as conv_igemm in another order (32-channel sub-chunks), so the two agree to fp32
-    accumulation noise under the fp16 output rounding, not bit for bit -- which is why the engine chooses it by the layer's shape and
-    map size alone, never by the batch.  Checked: against conv_igemm (at most the last fp16 bit, rarely), against torch fp64 at fp16
-    accuracy, and image 0 alone == image 0 inside the batch, bit for bit."""
+    """conv_ht.hip walks the reduction in 32-channel chunks (its halo images are 32 channels deep), conv_igemm's fp16 kernels in
+    64-channel chunks: same products, another summation order, so the two agree to fp32 accumulation noise under the fp16 output
+    rounding, not bit for bit.  The engine therefore decides at weight-packing time, from the layer's shape and map size alone,
+    which order a layer uses; a layer packed for conv_ht runs on conv_ht when the batch fills the chip with its tiles and on
+    conv_igemm's 32-channel-chunk tiles (`c32`) when it does not -- and THOSE two must agree bit for bit, or a sample's result would
+    depend on its batch.  Checked: conv_ht == c32 tiles bitwise; against the 64-chunk kernel (at most the last fp16 bit, rarely);
+    against torch fp64 at fp16 accuracy; image 0 alone == image 0 inside the batch, bit for bit."""
     a, ka, (x, w, b, res, relu) = _run_conv_f16(shape, 3)
+    e, ke, _ = _run_conv_f16(shape, 4)
     c, kc, _ = _run_conv_f16(shape, 1)
-    assert ka.startswith("conv_ht_f16") and kc.startswith("conv_igemm_f16"), (ka, kc)
+    assert ka.startswith("conv_ht_f16") and ke.startswith("conv_igemm_f16") and ke.endswith("c32>") and kc.startswith("conv_igemm_f16"), (ka, ke, kc)
+    assert torch.equal(a.view(torch.int16), e.view(torch.int16)), (ka, ke, (a.float() - e.float()).abs().max())
     assert torch.isfinite(a.float()).all()
     d = (a.float() - c.float()).abs()
     scale = c.float().abs().max().item()
@@ -360,7 +365,7 @@ def test_tall_tile_kernel(shape):
         out = torch.full((1,) + tuple(a.shape[1:]), float("nan"), device=dev, dtype=torch.float16)
         wc, bc = w.contiguous().numpy(), b.contiguous().numpy()
         rc = lib.hmv_op_conv2d_f16(0, x0.data_ptr(), 1, one[1], one[2], one[3], wc.ctypes.data_as(ctypes.c_void_p),
-                                   bc.ctypes.data_as(ctypes.c_void_p), one[4], 3, 3, 1, 1, None, int(relu), out.data_ptr(), 3, None, None)
+                                   bc.ctypes.data_as(ctypes.c_void_p), one[4], 3, 3, 1, 1, None, int(relu), out.data_ptr(), 4, None, None)   # on the small-batch tiles
         assert rc == 0, lib.hmv_last_error(None)
         assert torch.equal(out.cpu()[0].view(torch.int16), a[0].view(torch.int16))
 

@@ -1,0 +1,11 @@
+O=gpurun_out/r03; mkdir -p $O
+for b in 1 2 4; do
+  timeout -k 10 300 python bench.py --dtype f16 --no-cpu-baseline --batch $b --steps 100 --warmup 10 > $O/b${b}_ht.json 2> $O/b${b}_ht.err || exit 56
+  HMV_NO_HT=1 timeout -k 10 300 python bench.py --dtype f16 --no-cpu-baseline --batch $b --steps 100 --warmup 10 > $O/b${b}_noht.json 2> $O/b${b}_noht.err || exit 57
+done
+python - <<'PY'
+import json
+for b in (1, 2, 4):
+    for tag in ("ht", "noht"):
+        d = json.load(open(f"gpurun_out/r03/b{b}_{tag}.json")); print("B", b, tag, d["ms_per_step"])
+PY

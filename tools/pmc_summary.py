@@ -32,11 +32,12 @@ def family(name: str) -> str:
         skip = ",rowsum" if m.group(7) == "true" else (",skipN" if m.group(6) == "true" else "")
         return f"conv_igemm_{t}<{m.group(2)}x{m.group(3)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense", "3": "halo"}[m.group(4)] + skip + ">"
     # rocprofv3 leaves the _Float16 instantiations mangled (DF16_): conv_igemm<_Float16, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD>
-    m = re.match(r"_ZN3hmv10conv_igemmIDF16_Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)ELb[01]ELi(\d+)ELb[01]ELb([01])E", name)
+    m = re.match(r"_ZN3hmv10conv_igemmIDF16_Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)ELb[01]ELi(\d+)ELb[01]ELb([01])E(?:Lb[01]ELb([01])E)?", name)
     if m:
-        k16 = ",k16" if m.group(4) == "32" else ""
+        c32 = m.group(6) == "1"   # the 32-channel-chunk K order of the layers packed for conv_ht.hip
+        k16 = ",k16" if (m.group(4) == "32" and not c32) else ""
         return f"conv_igemm_f16<{m.group(1)}x{m.group(2)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense", "3": "halo"}[m.group(3)] + \
-            (",rowsum" if m.group(5) == "1" else "") + ">"
+            (",rowsum" if m.group(5) == "1" else "") + (",c32" if c32 else "") + ">"
     # round 3: conv_stream_f16<TM, TN, MW, NW, NP, NSLOT, HAS_RES, SPREAD, NT> and conv_gemm8_f16<DUAL>
     m = re.match(r"(?:void )?(?:hmv::)?conv_stream_f16<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, (true|false)", name)
     if m:
@@ -50,6 +51,8 @@ def family(name: str) -> str:
         r_, s_, cpp, tn, nw = (int(m.group(i)) for i in range(1, 6))
         cout = 40 if cpp == 5 else 32 * tn * nw
         return f"conv_hs_f16<{r_}x{s_},{8 * cpp}->{cout}" + (",res>" if m.group(6) == "true" else ">")
+    if re.match(r"(?:void )?(?:hmv::)?conv_ht_f16\b", name) or name.startswith("_ZN3hmv11conv_ht_f16"):
+        return "conv_ht_f16<512x128,3x3>"
     m = re.match(r"(?:void )?(?:hmv::)?conv_gemm8_f16<(true|false)>", name)
     if m:
         return "conv_gemm8_f16<256x256,1x1" + (",dual>" if m.group(1) == "true" else ">")

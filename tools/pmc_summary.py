@@ -25,11 +25,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def family(name: str) -> str:
     """rocprofv3 symbol -> the kernel family name bench.py / the engine use (one symbol per family)."""
-    m = re.match(r"(?:void )?(?:hmv::)?conv_igemm<(float|_Float16), (\d+), (\d+), \d+, \d+, (\d), (?:false|true), (\d+)(?:, (false|true))?(?:, (false|true))?(?:, (?:false|true))?>", name)
+    m = re.match(r"(?:void )?(?:hmv::)?conv_igemm<(float|_Float16), (\d+), (\d+), \d+, \d+, (\d), (?:false|true), (\d+)(?:, (false|true))?(?:, (false|true))?(?:, (?:false|true))?(?:, (false|true))?>", name)
     if m:
         t = "f32" if m.group(1) == "float" else "f16"
         k16 = ",k16" if (t == "f32" and m.group(5) == "16") else ""
         skip = ",rowsum" if m.group(7) == "true" else (",skipN" if m.group(6) == "true" else "")
+        skip += ",c32" if m.group(8) == "true" else ""
         return f"conv_igemm_{t}<{m.group(2)}x{m.group(3)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense", "3": "halo"}[m.group(4)] + skip + ">"
     # rocprofv3 leaves the _Float16 instantiations mangled (DF16_): conv_igemm<_Float16, BM, BN, WGM, WGN, MODE, GENERIC, KB, PARTN, RD>
     m = re.match(r"_ZN3hmv10conv_igemmIDF16_Li(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d)ELb[01]ELi(\d+)ELb[01]ELb([01])E(?:Lb[01]ELb([01])E)?", name)
@@ -60,7 +61,8 @@ def family(name: str) -> str:
 
 
 def load(d):
-    return list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0])))
+    files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+    return list(csv.DictReader(open(max(files, key=os.path.getmtime))))   # the newest pass if older ones were merged into the directory
 
 
 def main():

@@ -951,7 +951,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
         } else if (vec) {
             if constexpr (!F16) {   // the fp32 kernels keep their hand-tuned 4-wide drain (any restructuring here costs ~3 %)
             constexpr int TPR = BN / 4, RPP = NT / TPR, NPASS = SR / RPP, UB = NPASS < HMV_UB ? NPASS : HMV_UB;
-            static_assert(SR % RPP == 0 && NPASS % UB == 0, "staging pass shape");
+            static_assert(TOUT || (SR % RPP == 0 && NPASS % UB == 0), "staging pass shape");   // (the register-epilogue kernels never get here)
             const int c4 = tid % TPR, r0 = tid / TPR;
             const int col = n0 + 4 * c4;
             // columns [Cout, round4(Cout)) hold exact zeros (zero-padded weights and bias): writing them is
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, min_waves(BM, BN, 64 * WGM * WGN, s
             auto drain = [&](auto wtag) {
                 constexpr int W = decltype(wtag)::value, W4 = W / 4;
                 constexpr int TPR = BN / W, RPP = NT / TPR, NPASS = SR / RPP, UB = NPASS < HMV_UB_F16 ? NPASS : HMV_UB_F16;
-                static_assert(SR % RPP == 0 && NPASS % UB == 0, "staging pass shape");
+                static_assert(TOUT || (SR % RPP == 0 && NPASS % UB == 0), "staging pass shape");   // (the register-epilogue kernels never get here)
                 const int cw = tid % TPR, r0 = tid / TPR;
                 const int col = n0 + W * cw;
                 // columns [Cout, round4(Cout)) hold exact zeros (zero-padded weights and bias): writing them is
@@ -1440,6 +1440,13 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     }
     if (dense) {   // dense K order over the real channels (stem, HRNet's 40 / 80-channel tensors)
         if (p.in_f16) {
+            // 129 .. 192 output channels (HRNet-w40's 160-channel branch): ONE 192-wide N-tile instead of two 128-wide ones whose
+            // second is three quarters padding (6 instead of 8 MFMA column blocks per pixel block)
+            static const bool no192 = getenv("HMV_NO_N192") != nullptr;   // development knob (A/B runs)
+            if (tile == TILE_256x128 && p.Cout > 128 && p.Cout <= 192 && !generic && !no192) {
+                if (name) *name = "conv_igemm_f16<256x192,dense>";
+                return launch_one<_Float16, 256, 192, 4, 2, MODE_DENSE, false, 64>(p, s);
+            }
             switch (tile) {
                 case TILE_128x32: return launch_one<_Float16, 128, 32, 4, 1, MODE_DENSE, false, 64>(p, s);
                 case TILE_128x64: return launch_one<_Float16, 128, 64, 2, 2, MODE_DENSE, false, 64>(p, s);

@@ -370,6 +370,26 @@ def test_tall_tile_kernel(shape):
         assert torch.equal(out.cpu()[0].view(torch.int16), a[0].view(torch.int16))
 
 
+@pytest.mark.parametrize("shape", [(256, 16, 16, 160, 160, 3, 1, 1, True, True), (256, 16, 16, 160, 160, 3, 1, 1, False, False),
+                                   (300, 16, 16, 80, 136, 3, 1, 1, False, True)])
+def test_wide_n_tile_192(shape):
+    """HRNet-w40's 160-channel branch at bench size (hrnet.py:96-221): 129 .. 192 output channels run on ONE 256 x 192 tile per
+    256 pixels instead of two 128-wide ones.  Checked against torch fp64 on three of the images (the whole batch in fp64 on the
+    CPU would take minutes) and for finiteness everywhere."""
+    a, ka, (x, w, b, res, relu) = _run_conv_f16(shape, 0)
+    assert ka == "conv_igemm_f16<256x192,dense>", ka
+    assert torch.isfinite(a.float()).all()
+    for i in (0, shape[0] // 2, shape[0] - 1):
+        ref = torch.nn.functional.conv2d(x[i:i + 1].half().double().permute(0, 3, 1, 2), w.half().double(), b.double(), stride=1,
+                                         padding=1).permute(0, 2, 3, 1)
+        if res is not None:
+            ref = ref + res[i:i + 1].half().double()
+        if relu:
+            ref = ref.clamp_min(0)
+        err = (a[i:i + 1].double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-3, (i, err)
+
+
 def _random_conv_shapes(n, seed):
     rng = np.random.default_rng(seed)
     shapes = []

@@ -42,6 +42,15 @@ __device__ __forceinline__ void hs_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <typename F, int... I>
+__device__ __forceinline__ void hs_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void hs_static_for(F &&f) {
+    hs_static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
 // A block's vector-memory instructions, in issue order: HP halo DMAs (block t + D), RB residual DMAs (block t + 1), OS stores.
 // "X landed" == "at most the instructions issued after X are still out".
 constexpr int hs_after_halo(int D, int HP, int RB, int OS) { return RB + OS + (D - 1) * (HP + RB + OS); }   // waited at the top of block t
@@ -50,20 +59,23 @@ constexpr int hs_after_residual(int HP, int RB, int OS) { return OS + HP + RB; }
 // R x S taps over pixels of CPP 16-byte chunks (8 channels each): K is the plain (r, s, c) order, so chunk g = (tap g / CPP, channels
 // 8 (g % CPP) ..) and k16 step Q multiplies chunks 2Q (lanes 0-31) and 2Q + 1 (lanes 32-63) -- which may belong to two taps when
 // CPP is odd (HRNet-w40's 40-channel pixels).  Wave grid MW x NW over (pixel blocks x channel blocks); TM 32-pixel blocks (= two
-// rows of the 16 x 16 output block) and TN 32-channel blocks per wave; MW * TM == 8.
+// rows of the BH x 16 output block) and TN 32-channel blocks per wave; BH = 2 MW TM is 16 (eight waves) or, where the weights of
+// a 32-channel block take most of a wave's registers (80 -> 80 channels: 180 of them), 8 rows under THREE waves (one per
+// 32-channel block, one wave per SIMD: each may then use the 512 registers of its SIMD lane).
 template <int R, int S, int CPP, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES>
-__global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
-    constexpr int NWV = MW * NW;
-    constexpr int HH = 16 + R - 1, HW = 16 + S - 1, HROWS = HH * HW;
+__global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f16(const ConvParams p) {
+    constexpr int NWV = MW * NW, NT = 64 * NWV;
+    constexpr int BH = 2 * MW * TM;                    // output rows of a block
+    constexpr int HH = BH + R - 1, HW = 16 + S - 1, HROWS = HH * HW;
     constexpr int NCH = R * S * CPP;                   // 16-byte chunks of the reduction
-    constexpr int HP = (HROWS * CPP + 511) / 512;      // DMA instructions per halo image and thread
-    constexpr int SLOT = HP * 8192;                    // bytes of one halo image (padded to whole passes)
+    constexpr int HP = (HROWS * CPP + NT - 1) / NT;    // DMA instructions per halo image and thread
+    constexpr int SLOT = HP * NT * 16;                 // bytes of one halo image (padded to whole passes)
     constexpr int D = NSLOT - 1;
     constexpr int RB = HAS_RES ? TM * TN * 2 : 0, OS = TM * TN * 2;
     constexpr int ZW = TM * TN * 2 * 1024;
     constexpr int NSTEP = (NCH + 1) / 2;
     constexpr bool SWZ = CPP == 8;                     // 128-byte pixels: XOR swizzle; 80- / 32-byte pixels are conflict-free as they lie
-    static_assert(NWV == 8 && MW * TM == 8, "eight waves over eight 32-pixel blocks");
+    static_assert(NWV <= 8 && (BH == 16 || BH == 8), "at most eight waves over 16 x 16 or 8 x 16 output blocks");
     extern __shared__ __attribute__((aligned(16))) char hsm[];
     char *zones = hsm + NSLOT * SLOT;                  // [2][NWV][ZW]
 
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
     const int n0 = nw * TN * 32;                       // this wave's first output channel
 
     // ---- the blocks of this workgroup: b = blockIdx.x, + gridDim.x, ...
-    const int tyn = p.Ho >> 4, txn = p.Wo >> 4, per_img = tyn * txn, nblk = p.N * per_img;
+    const int tyn = p.Ho / BH, txn = p.Wo >> 4, per_img = tyn * txn, nblk = p.N * per_img;
     const int ntl = nblk > (int)blockIdx.x ? (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     if (ntl == 0) return;
 
@@ -84,7 +96,8 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
     const _Float16 *Rin = reinterpret_cast<const _Float16 *>(p.res);
     _Float16 *Out = reinterpret_cast<_Float16 *>(p.out);
 
-    // ---- weights -> registers, once: block b, step Q: the 8 halfs k = 16 Q + 8 kh .. of row
+    // ---- weights -> registers, once (issuing them behind the first halo requests instead measured the same: the launch's fixed
+    // ~9 us are not their latency): block b, step Q: the 8 halfs k = 16 Q + 8 kh .. of row
     // swap23(l31) (conv_igemm's transposed-output convention: registers 8j .. 8j+7 are eight consecutive channels)
     const int wl31 = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
     hf16x8 wreg[TN][NSTEP];
@@ -99,11 +112,15 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
 
     // ---- halo DMA roles, block-invariant: pass i moves 16-byte unit L = 512 i + tid of the image = chunk L % CPP of halo pixel
     // L / CPP (with 128-byte pixels the chunk it FETCHES is XOR-swizzled so that the lane-linear LDS image is conflict-free)
-    int hyx[HP];   // row << 16 | column << 8 | source chunk; units past the halo get row 200: always out of the image -> zero page
+    // row << 24 | column << 16 | element offset of (column, source chunk) inside an image row (lda == Cin == 8 CPP: conv_hs_supported);
+    // units past the halo get row 200: always out of the image -> zero page
+    int hyx[HP];
 #pragma unroll
     for (int i = 0; i < HP; ++i) {
-        const int L = 512 * i + tid, hp = L / CPP, ch = L - hp * CPP;
-        hyx[i] = ((hp < HROWS ? hp / HW : 200) << 16) | ((hp - (hp / HW) * HW) << 8) | (SWZ ? (ch ^ ((hp >> 1) & 7)) : ch);
+        const int L = NT * i + tid, hp = L / CPP, ch = L - hp * CPP;
+        const int hx = hp - (hp / HW) * HW;
+        static_assert(8 * (HW * CPP + CPP) < 65536, "column offset field");
+        hyx[i] = ((hp < HROWS ? hp / HW : 200) << 24) | (hx << 16) | (8 * (hx * CPP + (SWZ ? (ch ^ ((hp >> 1) & 7)) : ch)));
     }
 
     auto block_origin = [&](int tt, int &n, int &by, int &bx) {
@@ -120,11 +137,16 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
         char *dst = hsm + (((tt % NSLOT) + NSLOT) % NSLOT) * SLOT + wave * 1024;
 #pragma unroll
         for (int i = 0; i < HP; ++i) {
-            const int iy = by * 16 - p.pad_h + (hyx[i] >> 16), ix = bx * 16 - p.pad_w + ((hyx[i] >> 8) & 255);
-            const bool ok = live && (hyx[i] >> 16) < 200 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const _Float16 *src = ok ? Ain + ((size_t)(n * p.H + iy) * p.W + ix) * p.lda + 8 * (hyx[i] & 255) : zero16;
+            int h = hyx[i];
+            asm volatile("" : "+v"(h));   // its fields are this block's arithmetic: hoisted, each would hold a register for the launch
+            const int iy = by * BH - p.pad_h + (int)((unsigned)h >> 24), ix0 = bx * 16 - p.pad_w, ix = ix0 + ((h >> 16) & 255);
+            const bool ok = live && ((unsigned)h >> 24) < 200 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            // (32-bit element index: conv_hs_supported keeps N H W lda below 2^31.  A 64-bit form lets the compiler keep one
+            // block-invariant base POINTER per pass: ten registers the 80-channel variant does not have)
+            // (unsigned: a wrapping sum is extended to 64 bits as a whole, not term by term)
+            const _Float16 *src = ok ? Ain + ((unsigned)(((n * p.H + iy) * p.W + ix0) * (8 * CPP)) + ((unsigned)h & 0xffffu)) : zero16;
             asm volatile("" : "+v"(src));   // ONE DMA instruction per schedule entry
-            HMV_HGLDS16(src, dst + i * 8192);
+            HMV_HGLDS16(src, dst + i * (NT * 16));
         }
     };
     // pixel of lane l31 in 32-pixel block a of this wave: output row 2 (mw TM + a) + (l31 >> 4), column l31 & 15
@@ -136,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
             char *z = zones + ((tt & 1) * NWV + wave) * ZW;
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                const size_t pix = (size_t)(n * p.Ho + by * 16 + 2 * (mw * TM + a) + (l31 >> 4)) * p.Wo + bx * 16 + (l31 & 15);
+                const size_t pix = (size_t)(n * p.Ho + by * BH + 2 * (mw * TM + a) + (l31 >> 4)) * p.Wo + bx * 16 + (l31 & 15);
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
@@ -191,14 +213,13 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
         // spills them (the weights hold up to 144 registers).  An opaque zero makes them this block's own arithmetic.
         int hz;
         asm volatile("v_mov_b32 %0, 0" : "=v"(hz));
-#pragma unroll
-        for (int Q = 0; Q < NSTEP; ++Q) {
-            // chunk of lanes 0-31 / 32-63 (a chunk past the reduction's end multiplies zero weights: any finite pixel will do)
+        // pixel fragments of step Q (chunk of lanes 0-31 / 32-63; a chunk past the reduction's end multiplies zero weights: any
+        // finite pixel will do)
+        auto load_px = [&](int Q, hf16x8 (&px)[TM]) {
             constexpr int dummy = 0;
             const int gA = 2 * Q < NCH ? 2 * Q : dummy, gB = 2 * Q + 1 < NCH ? 2 * Q + 1 : dummy;
             const int tA = gA / CPP, cA = gA - tA * CPP, tB = gB / CPP, cB = gB - tB * CPP;
             const int oA = (tA / S) * HW + tA % S, oB = (tB / S) * HW + tB % S;   // halo pixel offset of the tap
-            hf16x8 px[TM];
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 if constexpr (SWZ) {   // CPP == 8: both chunks belong to one tap
@@ -209,13 +230,58 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
                     px[a] = *reinterpret_cast<const hf16x8 *>(himg + u * 16);
                 }
             }
+        };
+        // One wave per SIMD (the three-wave variant) has nobody to hide an LDS round trip behind.  Its fragments of step Q + 1 are
+        // requested BEFORE the MFMAs of step Q, into the other of two register sets, and waited for with a COUNTED lgkmcnt: the
+        // reads are inline asm (the compiler, left to track them, reuses one register set and drains the LDS queue before every MFMA
+        // group -- 3x the MFMA time), the wait names the registers it releases so that no MFMA can move above it.
+        constexpr bool PIPE = !SWZ && CPP % 2 == 0 && CPP > 2;   // (the stem's 32-byte pixels keep the plain loop)
+        hf16x8 pxs[2][TM];
+        if constexpr (PIPE) {
+            // an even CPP keeps the two chunks of a k16 step inside one tap: lanes 32-63 read 16 bytes behind lanes 0-31, and the
+            // step's own displacement is an instruction immediate -- four address registers per block, no per-step arithmetic
+            static_assert(!SWZ && CPP % 2 == 0 && NCH % 2 == 0, "the pipelined variant: unswizzled pixels, whole chunk pairs per tap");
+            unsigned vb[TM];
 #pragma unroll
             for (int a = 0; a < TM; ++a)
+                vb[a] = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)himg + (unsigned)(((hb[a] + hz) * CPP + kh) * 16);
+            auto load_asm = [](auto Qc, hf16x8 (&px)[TM], const unsigned (&vbr)[TM]) {
+                constexpr int Q = decltype(Qc)::value, tA = (2 * Q) / CPP, cA = 2 * Q - tA * CPP;
+                constexpr int off = (((tA / S) * HW + tA % S) * CPP + cA) * 16;
+                static_assert(off < 65536, "ds_read offset field");
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[b][Q], px[a], acc[a][b], 0, 0, 0);
-            // keep the scheduler from hoisting every step's address arithmetic and fragment reads to the top of the block
-            if ((Q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                for (int a = 0; a < TM; ++a) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(px[a]) : "v"(vbr[a]), "n"(off));
+            };
+            load_asm(std::integral_constant<int, 0>{}, pxs[0], vb);
+            hs_static_for<NSTEP>([&](auto Qc) {
+                constexpr int Q = decltype(Qc)::value;
+                if constexpr (Q + 1 < NSTEP) {
+                    load_asm(std::integral_constant<int, Q + 1>{}, pxs[(Q + 1) & 1], vb);
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(pxs[Q & 1][0]) : "n"(TM));   // the TM reads just issued may fly
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pxs[Q & 1][0]));
+                }
+#pragma unroll
+                for (int a = 1; a < TM; ++a) asm volatile("" : "+v"(pxs[Q & 1][a]));
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[b][Q], pxs[Q & 1][a], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
+#pragma unroll
+            for (int Q = 0; Q < NSTEP; ++Q) {
+                load_px(Q, pxs[0]);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[b][Q], pxs[0][a], acc[a][b], 0, 0, 0);
+                // keep the scheduler from hoisting every step's address arithmetic and fragment reads to the top of the block
+                if ((Q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // ---- epilogue
         if constexpr (HAS_RES) hs_wait_vm<hs_after_residual(HP, RB, OS)>();
@@ -224,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
         const char *z = zones + ((tt & 1) * NWV + wave) * ZW + lane * 16;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-            const size_t pix = (size_t)(n * p.Ho + by * 16 + 2 * (mw * TM + a) + (l31 >> 4)) * p.Wo + bx * 16 + (l31 & 15);
+            const size_t pix = (size_t)(n * p.Ho + by * BH + 2 * (mw * TM + a) + (l31 >> 4)) * p.Wo + bx * 16 + (l31 & 15);
             _Float16 *orow = Out + pix * p.ldc + n0 + 8 * kh;
 #pragma unroll
             for (int b = 0; b < TN; ++b)
@@ -240,6 +306,9 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
                     _Float16 *dst = (n0 + 32 * b + 16 * j + 8 * kh) < p.Cout ? orow + 32 * b + 16 * j : trash;
                     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(hv) : "memory");
                 }
+            // (the 80-channel variant holds 180 weight registers: finish one pixel block before the next one's residual vectors,
+            // accumulator copies and results become live)
+            if constexpr (CPP == 10) __builtin_amdgcn_sched_barrier(0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -249,12 +318,15 @@ __global__ __launch_bounds__(512, 2) void conv_hs_f16(const ConvParams p) {
 static int g_hs_mode = -1;   // -1: the launcher's rule (HMV_NO_HS=1 disables it); 0 never; 1 whenever supported (op-level tests)
 void conv_hs_set_mode(int mode) { g_hs_mode = mode; }
 
-// 0: no instantiation; 1: 3x3 pad 1, 64 -> 64 channels; 2: the 4x4 space-to-depth stem, 16 -> 64 channels; 3: 3x3 pad 1, 40 -> 40
-// channels in the plain (r, s, c) K order (HRNet-w40's highest-resolution branch, hrnet.py:96-221)
+// 0: no instantiation; 1: 3x3 pad 1, 64 -> 64 channels; 2: the 4x4 space-to-depth stem, 16 -> 64 channels; 3 / 4: 3x3 pad 1, 40 -> 40 /
+// 80 -> 80 channels in the plain (r, s, c) K order (HRNet-w40's two highest-resolution branches, hrnet.py:96-221; kind 4 on 8 x 16
+// blocks under three waves)
+static int hs_bh(int kind) { return kind == 4 ? 8 : 16; }
 static int hs_kind(const ConvParams &p) {
     if (p.R == 3 && p.S == 3 && p.pad_h == 1 && p.pad_w == 1 && p.Cin == 64 && p.Cout == 64 && p.Kpad == 576) return 1;
     if (p.R == 4 && p.S == 4 && p.pad_h == 2 && p.pad_w == 2 && p.Cin == 16 && p.Cout == 64 && p.Kpad == 256 && !p.res) return 2;
     if (p.R == 3 && p.S == 3 && p.pad_h == 1 && p.pad_w == 1 && p.Cin == 40 && p.Cout == 40 && p.Kpad == 384 && !p.rd_cout) return 3;
+    if (p.R == 3 && p.S == 3 && p.pad_h == 1 && p.pad_w == 1 && p.Cin == 80 && p.Cout == 80 && p.Kpad == 768 && !p.rd_cout) return 4;
     return 0;
 }
 
@@ -263,19 +335,21 @@ bool conv_hs_supported(const ConvParams &p) {
     if (off < 0) off = getenv("HMV_NO_HS") ? 1 : 0;
     if (g_hs_mode == 0 || (g_hs_mode < 0 && off)) return false;
     if (!hs_kind(p) || !p.in_f16 || !p.out_f16 || (p.res && !p.res_f16)) return false;
-    if (p.stride != 1 || p.up || p.in2 || p.ksl > 1 || p.phases > 1 || p.Ho != p.H || p.Wo != p.W || (p.H & 15) || (p.W & 15)) return false;
+    if (p.stride != 1 || p.up || p.in2 || p.ksl > 1 || p.phases > 1 || p.Ho != p.H || p.Wo != p.W || p.H % hs_bh(hs_kind(p)) || (p.W & 15)) return false;
     if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out) return false;
     if (p.fill && p.ldc != p.Cout) return false;   // (pad columns to clear: conv_igemm's epilogue does that)
     if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
     if ((p.lda ? p.lda : p.Cin) != p.Cin || ((p.ldw ? p.ldw : p.Kpad) & 7) || (p.ldc & 7) || (p.res && (p.ldr & 7))) return false;
+    if ((long long)p.N * p.H * p.W * p.Cin >= (1ll << 31)) return false;   // 32-bit element offsets of the halo pixels
     if (g_hs_mode > 0) return true;
-    return (long long)p.N * (p.H >> 4) * (p.W >> 4) >= 4 * 256;   // at least four blocks per workgroup
+    return (long long)p.N * (p.H / hs_bh(hs_kind(p))) * (p.W >> 4) >= 4 * 256;   // at least four blocks per workgroup
 }
 
 template <int R, int S, int CPP, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES>
 static hipError_t launch_hs_one(const ConvParams &p, hipStream_t s) {
-    constexpr int HROWS = (16 + R - 1) * (16 + S - 1), HP = (HROWS * CPP + 511) / 512;
-    constexpr size_t lds = (size_t)NSLOT * HP * 8192 + (HAS_RES ? (size_t)2 * 8 * TM * TN * 2 * 1024 : 0);
+    constexpr int NWV = MW * NW, NT = 64 * NWV, BH = 2 * MW * TM;
+    constexpr int HROWS = (BH + R - 1) * (16 + S - 1), HP = (HROWS * CPP + NT - 1) / NT;
+    constexpr size_t lds = (size_t)NSLOT * HP * NT * 16 + (HAS_RES ? (size_t)2 * NWV * TM * TN * 2 * 1024 : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool configured[64] = {};
     auto kern = conv_hs_f16<R, S, CPP, TM, TN, MW, NW, NSLOT, HAS_RES>;
@@ -286,8 +360,8 @@ static hipError_t launch_hs_one(const ConvParams &p, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured[dev] = true;
     }
-    const int nblk = p.N * (p.H >> 4) * (p.W >> 4);
-    hipLaunchKernelGGL(kern, dim3(nblk < 256 ? nblk : 256), dim3(512), lds, s, p);
+    const int nblk = p.N * (p.H / BH) * (p.W >> 4);
+    hipLaunchKernelGGL(kern, dim3(nblk < 256 ? nblk : 256), dim3(NT), lds, s, p);
     return hipGetLastError();
 }
 
@@ -310,6 +384,13 @@ hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name)
             }
             if (name) *name = "conv_hs_f16<3x3,40->40>";
             return launch_hs_one<3, 3, 5, 2, 1, 4, 2, 4, false>(p, s);
+        case 4:   // 80-channel pixels, 96 weight rows on three channel waves (one per SIMD, up to 512 registers each): 8 x 16 blocks, 30 KB halo images
+            if (p.res) {
+                if (name) *name = "conv_hs_f16<3x3,80->80,res>";
+                return launch_hs_one<3, 3, 10, 2, 1, 2, 3, 3, true>(p, s);
+            }
+            if (name) *name = "conv_hs_f16<3x3,80->80>";
+            return launch_hs_one<3, 3, 10, 2, 1, 2, 3, 4, false>(p, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -574,6 +574,8 @@ int hmv_finalize_weights(hmv_handle h) {
         // that the weight-stationary halo-streaming kernel (conv_hs.hip: 1.9 -> ~4 TB/s on these layers) takes the large batches
         // and conv_igemm's dense mode -- same K order, same bits -- the small ones.  Decided by the configuration, never by the batch.
         if (h16 && !L.split && hr.ch[0] == 40 && c.height % 64 == 0 && c.width % 64 == 0 && !getenv("HMV_NO_HS")) rdb[0] = false;
+        // ... and the 80-channel branch (H/8 x W/8 maps in 8 x 16 blocks; conv_hs.hip's three-wave variant)
+        if (h16 && !L.split && hr.ch[1] == 80 && c.height % 64 == 0 && c.width % 128 == 0 && !getenv("HMV_NO_HS") && !getenv("HMV_NO_HS80")) rdb[1] = false;
         const bool rd0 = rdb[0];
         L.conv(hr.conv1, "stem.conv1", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 3, 3, /*cin_pad=*/h16 ? 8 : 4, h16);
         L.conv(hr.conv2, "stem.conv2", "backbone.conv2.weight", "", "backbone.bn2", 64, 64, 3, 3, 0, h16);

@@ -276,7 +276,10 @@ HS_SHAPES = [(4, 32, 32, 64, 64, 3, 1, 1, False, True), (3, 48, 16, 64, 64, 3, 1
              (40, 64, 64, 64, 64, 3, 1, 1, False, True), (24, 64, 32, 64, 64, 3, 1, 1, True, False),
              # 40 -> 40 channels (HRNet-w40's highest-resolution branch): 80-byte pixels, two taps inside one MFMA step
              (4, 32, 32, 40, 40, 3, 1, 1, False, True), (3, 48, 16, 40, 40, 3, 1, 1, True, True), (40, 64, 64, 40, 40, 3, 1, 1, True, True),
-             (1, 16, 16, 40, 40, 3, 1, 1, True, False)]
+             (1, 16, 16, 40, 40, 3, 1, 1, True, False),
+             # 80 -> 80 channels (w40's second branch): 160-byte pixels, 8 x 16 blocks, three waves with the weights of 32 channels each
+             (8, 32, 32, 80, 80, 3, 1, 1, False, True), (3, 24, 16, 80, 80, 3, 1, 1, True, True), (40, 32, 32, 80, 80, 3, 1, 1, True, True),
+             (1, 8, 16, 80, 80, 3, 1, 1, True, False)]
 
 
 def _run_conv_f16(shape, sel):

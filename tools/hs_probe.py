@@ -13,7 +13,9 @@ def main():
     os.environ.setdefault("HMV_BENCH_DTYPE", "f16")
     n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     lib = _lib.load()
-    for name, H, Cin, Cout, k, pad, res in (("l1 conv2 3x3 64->64", 64, 64, 64, 3, 1, 0), ("r18 l1 3x3 64->64 +res", 64, 64, 64, 3, 1, 1)):
+    for name, H, Cin, Cout, k, pad, res in (("l1 conv2 3x3 64->64", 64, 64, 64, 3, 1, 0), ("r18 l1 3x3 64->64 +res", 64, 64, 64, 3, 1, 1),
+                                            ("w40 b0 3x3 40->40 +res", 64, 40, 40, 3, 1, 1), ("w40 b1 3x3 80->80", 32, 80, 80, 3, 1, 0),
+                                            ("w40 b1 3x3 80->80 +res", 32, 80, 80, 3, 1, 1)):
         ms = ctypes.c_float()
         rc = lib.hmv_bench_conv(0, n_img, H, H, Cin, Cout, k, k, 1, pad, res, -1, 20, ctypes.byref(ms))
         if rc:

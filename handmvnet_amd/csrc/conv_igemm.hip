@@ -1444,6 +1444,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
             // second is three quarters padding (6 instead of 8 MFMA column blocks per pixel block)
             static const bool no192 = getenv("HMV_NO_N192") != nullptr;   // development knob (A/B runs)
             if (tile == TILE_256x128 && p.Cout > 128 && p.Cout <= 192 && !generic && !no192) {
+                // (128 x 192 tiles, two 4-wave workgroups per CU, measured 28 % slower on the one-round launches of HRNet-w40: 3.82 vs 2.98 ms)
                 if (name) *name = "conv_igemm_f16<256x192,dense>";
                 return launch_one<_Float16, 256, 192, 4, 2, MODE_DENSE, false, 64>(p, s);
             }

@@ -9,18 +9,20 @@
 // better on gfx950 (its "256^2 8-phase template"); this is that structure for our operand roles and tile decomposition:
 //
 //   * a k-step is FOUR phases, each {fragment reads . DMA of one half-tile . [counted wait] . barrier . 8 MFMAs . barrier}:
-//         phase   MFMAs (pixel blocks a, channel block b)   fragment reads          DMA issued (tile t + 1)   wait
-//           1     a = 0,1  b = 0                            P[0,1] (8), W0 (4)      pixel half 0              vmcnt(4)
-//           2     a = 0,1  b = 1                            W1 (4)                  weight half 0             vmcnt(4)
-//           3     a = 2,3  b = 1                            P[2,3] (8)              weight half 1             --
-//           4     a = 2,3  b = 0                            --                      pixel half 1              vmcnt(4)
+//         phase   MFMAs (pixel blocks a, channel block b)   fragment reads          DMA issued                      wait
+//           1     a = 0,1  b = 0                            P[0,1] (8), W0 (4)      pixel half 1 of tile t + 1      vmcnt(10)
+//           2     a = 0,1  b = 1                            W1 (4)                  pixel half 0 of tile t + 2      vmcnt(10)
+//           3     a = 2,3  b = 1                            P[2,3] (8)              weight half 0 of tile t + 2     --
+//           4     a = 2,3  b = 0                            --                      weight half 1 of tile t + 2     vmcnt(10)
 //     a wave's 128 x 64 sub-tile = 4 x 2 accumulator blocks; every block gets the four k16 MFMAs of the step inside ONE phase,
 //     in ascending k: the same accumulation order as conv_igemm, hence the same bits.
 //   * the two wave halves (pixel rows 0-127 / 128-255) run ONE BARRIER APART: while one half issues its 8 MFMAs the other
 //     reads fragments and issues DMAs, so each SIMD's matrix pipe alternates between its two waves instead of idling.
-//   * `s_waitcnt vmcnt(4)`, never 0: a half-tile is two DMA instructions per thread, two half-tiles are always in flight across
-//     the barriers (raw s_barrier + lgkmcnt only).  A half-tile is read one phase after the wait that retires it (the wait
-//     precedes a barrier that every reader passes); a buffer is restaged a full k-step after its last read.
+//   * `s_waitcnt vmcnt(10)`, never 0: a half-tile is two DMA instructions per thread and its slot is refilled in the phase after
+//     the one that read it, so FIVE half-tiles (80 KB) are in flight across the barriers (raw s_barrier + lgkmcnt only): the
+//     pixel tiles come from HBM at 2-4 us per request under chip-wide load (the first version kept two half-tiles in flight:
+//     layer3 conv1 172 -> 162 us).  A half-tile is read one phase after the wait that retires it (the wait precedes a barrier that
+//     every reader passes).
 //   * LDS: 2 k-steps x 4 half-tiles x [128 rows][64 halfs] = 128 KB, XOR-swizzled on the DMA source side like conv_igemm.
 //     Half-tiles are cut along the phase boundaries: pixel half h = blocks 2h, 2h + 1 of both wave rows; weight half h =
 //     block h of all four wave columns.
@@ -159,14 +161,24 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8_f16(const ConvParams p) {
 #define G8_BAR()                                                                                            \
     asm volatile("s_barrier" ::: "memory");                                                                 \
     __builtin_amdgcn_sched_barrier(0)
-#define G8_WAIT4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+// Five half-tiles (80 KB) stay in flight: a half-tile's slot is refilled -- with the half-tile of k-step t + 2 -- in the phase after
+// the one whose fragment reads emptied it, not a whole k-step later.  The operand tiles come from HBM (the weights from L2): at the
+// 2-4 us a request takes under chip-wide load, 32 KB in flight were 10-16 GB/s per CU where HBM gives each CU 24 (tools/probe/l2bw.hip).
+// Issue order, two DMAs per phase:  ... P1: A1(t+1) . P2: A0(t+2) . P3: W0(t+2) . P4: W1(t+2) . P1: A1(t+2) ...
+// A half-tile is read 5 issues after its own: "at most 10 instructions out" == it has landed.  lgkmcnt(0) before a barrier: the
+// fragment reads of this phase have left LDS before any wave refills what they read.
+#define G8_WAIT10() asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory")
+#define G8_WAITLDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-    // ---- prologue: k-step 0 goes out whole in phase order; its first two half-tiles must have landed
+    // ---- prologue: the issue order of the steps "before the first"; A0(0) and W0(0) must have landed
     stage(0, 0);
     stage(0, 2);
     stage(0, 3);
     stage(0, 1);
-    G8_WAIT4();
+    stage(1, 0);
+    stage(1, 2);
+    stage(1, 3);
+    G8_WAIT10();
     G8_BAR();
     if (wm == 1) G8_BAR();   // the second wave half runs one barrier behind the first from here on
 
@@ -175,30 +187,31 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8_f16(const ConvParams p) {
         G8_READ_W(t, 0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         G8_READ_P(t, 0);
-        stage(t + 1, 0);
-        G8_WAIT4();            // weight half 1 of this k-step (read in phase 2) has landed
+        stage(t + 1, 1);       // (its slot: pixel half 1 of k-step t - 1, read in that step's phase 3)
+        G8_WAIT10();           // weight half 1 of this k-step (read in phase 2) has landed
         G8_BAR();
         G8_MFMA(0, 0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         G8_BAR();
         // phase 2
         G8_READ_W(t, 1, fb1);
-        stage(t + 1, 2);
-        G8_WAIT4();            // pixel half 1 of this k-step (read in phase 3) has landed
+        stage(t + 2, 0);       // (pixel half 0 of this k-step was read in phase 1)
+        G8_WAIT10();           // pixel half 1 of this k-step (read in phase 3) has landed
         G8_BAR();
         G8_MFMA(0, 1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         G8_BAR();
         // phase 3
         G8_READ_P(t, 1);
-        stage(t + 1, 3);
+        stage(t + 2, 2);       // (weight half 0: phase 1)
+        G8_WAITLDS();
         G8_BAR();
         G8_MFMA(2, 1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         G8_BAR();
         // phase 4
-        stage(t + 1, 1);
-        G8_WAIT4();            // pixel half 0 and weight half 0 of k-step t + 1 (read in its phase 1) have landed
+        stage(t + 2, 3);       // (weight half 1: phase 2)
+        G8_WAIT10();           // pixel half 0 and weight half 0 of k-step t + 1 (read in its phase 1) have landed
         G8_BAR();
         G8_MFMA(2, 0, fb0);
         __builtin_amdgcn_sched_barrier(0);
@@ -210,7 +223,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8_f16(const ConvParams p) {
 #undef G8_READ_W
 #undef G8_MFMA
 #undef G8_BAR
-#undef G8_WAIT4
+#undef G8_WAIT10
+#undef G8_WAITLDS
 
     // ---- epilogue straight from the accumulators (conv_igemm's register path without a residual):
     //   register 8j + u of block (a, b) = channel 32 b + 16 j + 8 kh + u of pixel row 32 a + l31
@@ -231,6 +245,184 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8_f16(const ConvParams p) {
                 for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + 0.f, lo);
                 if (m < p.M && col < cend) *reinterpret_cast<gf16x8 *>(orow + col) = hv;
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_gemm8r_f16: the same tile on 32-element k-steps with the two operand streams on SEPARATE waves.
+//
+// Vector-memory returns are in order per wave.  A wave that requests both operand tiles queues its weight lines -- L2 hits, back in
+// ~1 us, 117 GB/s per CU (tools/probe/l2bw.hip) -- behind its pixel lines, which come from HBM (24 GB/s per CU, 2-4 us under chip-wide
+// load): everything then pays the HBM latency, and a ring deep enough to cover it for BOTH operands does not fit LDS.  Here the first
+// wave half requests pixel tiles only, FIVE k-steps ahead (80 KB in flight, a ring of six 16 KB stages), the second half weight tiles
+// only, two k-steps ahead (a ring of three): each queue carries one latency class and its own counted wait (vmcnt(16) / vmcnt(4)).
+// Main loop: conv_ht.hip's -- one phase per k-step {12 fragment reads . 4 DMAs . wait . barrier . 16 MFMAs . barrier}, the wave halves one
+// barrier apart.  Accumulation order (k16 blocks ascending per accumulator block) and epilogue are conv_gemm8_f16's: same bits.
+constexpr int G8R_NA = 6, G8R_NW = 3, G8R_LA = G8R_NA - 1, G8R_LW = G8R_NW - 1, G8R_ST = 256 * 64;   // stages; bytes per stage
+constexpr int G8R_LDS = (G8R_NA + G8R_NW) * G8R_ST;                                                   // 147 456
+
+template <bool DUAL>
+__global__ __launch_bounds__(512, 2) void conv_gemm8r_f16(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char rsm[];   // [NA pixel stages][NW weight stages], each [256 rows][32 halfs]
+    char *wst = rsm + G8R_NA * G8R_ST;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    int mt, nt;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        mt = lid / p.ntiles;
+        nt = lid - mt * p.ntiles;
+    }
+    const _Float16 *zero = reinterpret_cast<const _Float16 *>(p.zero);
+    const int nk = p.Kpad >> 5;
+    unsigned long long t_entry = 0, t0c = 0, t0r = 0, t1c = 0, t1r = 0;   // diagnostic stamps (hmv_bench_conv with HMV_BENCH_CLOCK)
+    if (p.dbg) t_entry = __builtin_amdgcn_s_memrealtime();
+
+    // ---- DMA roles: 256 threads per operand; pass i moves 16-byte unit 256 i + (tid & 255) of a stage = physical chunk lane & 3 of
+    // row 64 i + ((tid & 255) >> 2), holding logical chunk (lane & 3) ^ ((row >> 2) & 3) (64-byte rows)
+    const int t8 = tid & 255, srow = t8 >> 2, sch = (t8 & 3) ^ ((t8 >> 4) & 3);
+    const bool pix_wave = wm == 0;
+    int off1[4], off2[4];              // pixel waves: element offsets of the four rows in the two sources (-1: past M -> zero page)
+    const _Float16 *wrow_src[4];       // weight waves: the four rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 64 * i + srow, m = mt * 256 + row;
+        off1[i] = m < p.M ? m * p.lda + 8 * sch : -1;
+        off2[i] = -1;
+        if constexpr (DUAL) {
+            if (m < p.M) {
+                const int hw = p.Ho * p.Wo, n = m / hw, rem = m - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                off2[i] = ((n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.lda2 + 8 * sch;
+            }
+        }
+        wrow_src[i] = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(nt * 256 + row) * p.ldw + 8 * sch;
+    }
+    const _Float16 *Ain = reinterpret_cast<const _Float16 *>(p.in), *Ain2 = reinterpret_cast<const _Float16 *>(p.in2);
+    // this wave's stage of k-step s (past the end: dummies from the zero page, nobody reads them)
+    auto issue = [&](int s) {
+        const bool live = s < nk;
+        const int k0 = s << 5;
+        char *dst = pix_wave ? rsm + (s % G8R_NA) * G8R_ST + (wave & 3) * 1024 : wst + (s % G8R_NW) * G8R_ST + (wave & 3) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const _Float16 *src = zero;
+            if (pix_wave) {
+                if constexpr (DUAL) {
+                    if (live && k0 >= p.ksplit) { if (off2[i] >= 0) src = Ain2 + (size_t)off2[i] + (k0 - p.ksplit); }
+                    else if (live && off1[i] >= 0) src = Ain + (size_t)off1[i] + k0;
+                } else {
+                    if (live && off1[i] >= 0) src = Ain + (size_t)off1[i] + k0;
+                }
+            } else if (live) {
+                src = wrow_src[i] + k0;
+            }
+            asm volatile("" : "+v"(src));   // ONE DMA instruction per schedule entry
+            HMV_GGLDS16(src, dst + i * 4096);
+        }
+    };
+
+    gf32x16 acc[4][2];
+    {
+        const float binit = 1.f / p.acc_scale;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float *bp = p.bias + nt * 256 + wn * 64 + 32 * b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const gf32x4 bq = *reinterpret_cast<const gf32x4 *>(bp + 16 * (q >> 1) + 8 * kh + 4 * (q & 1));
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[a][b][4 * q + u] = bq[u] * binit;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(acc[a][b]));   // the bias is in the accumulators before the first DMA goes out
+
+    // fragment addresses (bytes inside a stage): pixel block a = rows wm 128 + 32 a + l31; weight block b = rows wn 64 + 32 b + swap23(l31)
+    const int wl31 = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    int pfo[2], wfo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pr = wm * 128 + l31, wr = wn * 64 + wl31;   // (+ 32 a / 32 b leave (row >> 2) & 3 unchanged)
+        pfo[j] = (pr * 4 + ((2 * j + kh) ^ ((pr >> 2) & 3))) * 16;
+        wfo[j] = (wr * 4 + ((2 * j + kh) ^ ((wr >> 2) & 3))) * 16;
+    }
+    gf16x8 fp[4][2], fw[2][2];
+#define G8R_BAR()                                                                                           \
+    asm volatile("s_barrier" ::: "memory");                                                                 \
+    __builtin_amdgcn_sched_barrier(0)
+
+    // ---- prologue: each wave half fills its own ring's lead; stage 0 of both operands must have landed
+#pragma unroll
+    for (int s = 0; s < G8R_LA; ++s) if (pix_wave || s < G8R_LW) issue(s);
+    if (pix_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (G8R_LA - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (G8R_LW - 1)) : "memory");
+    G8R_BAR();
+    if (p.dbg) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+    if (wm == 1) { G8R_BAR(); }   // the second wave half runs one barrier behind the first from here on
+
+    for (int s = 0; s < nk; ++s) {
+        const char *ast = rsm + (s % G8R_NA) * G8R_ST, *bst = wst + (s % G8R_NW) * G8R_ST;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fw[b][j] = *reinterpret_cast<const gf16x8 *>(bst + wfo[j] + b * 32 * 64);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fp[a][j] = *reinterpret_cast<const gf16x8 *>(ast + pfo[j] + a * 32 * 64);
+        // the stage whose slot the previous step's reads emptied; then: my share of the next step's stage has landed, and this wave's
+        // fragment reads have left LDS
+        if (pix_wave) { issue(s + G8R_LA); asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (G8R_LA - 1)) : "memory"); }
+        else { issue(s + G8R_LW); asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (G8R_LW - 1)) : "memory"); }
+        G8R_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[b][j], fp[a][j], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        G8R_BAR();
+    }
+    if (wm == 0) { G8R_BAR(); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.dbg) { t1c = __builtin_amdgcn_s_memtime(); t1r = __builtin_amdgcn_s_memrealtime(); }
+#undef G8R_BAR
+
+    const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    const int nb0 = nt * 256 + wn * 64;
+    const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 7) & ~7);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int m = mt * 256 + wm * 128 + 32 * a + l31;
+        _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = nb0 + 32 * b + 16 * j + 8 * kh;
+                gf16x8 hv;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + 0.f, lo);
+                if (m < p.M && col < cend) *reinterpret_cast<gf16x8 *>(orow + col) = hv;
+            }
+    }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *d = p.dbg + 8 * (size_t)blockIdx.x;
+        d[0] = t1c - t0c; d[1] = t1r - t0r; d[2] = t_entry; d[3] = t0r; d[4] = t1r; d[5] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -272,6 +464,22 @@ hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name) {
     p.mtiles = (p.M + 255) / 256;
     p.ntiles = (p.Cout + 255) / 256;
     if (name) *name = p.in2 ? "conv_gemm8_f16<256x256,1x1,dual>" : "conv_gemm8_f16<256x256,1x1>";
+    // development knob, OFF by default: HMV_GEMM8_RING=1 selects conv_gemm8r_f16 (wave-specialised operand streams on a k32 ring).
+    // Measured 6 % SLOWER than the four-phase loop (layer3 conv1 172 vs 162 us, profiles/r03_probe_gemm8_ring.txt): these launches are
+    // bound by power, not by request latency (0.68 MFMA-busy in cycles at a 1.06-1.35 GHz clock on dense operands)
+    static const int ring = getenv("HMV_GEMM8_RING") ? atoi(getenv("HMV_GEMM8_RING")) : 0;
+    if (ring) {
+        static bool rconf[64] = {};
+        if (!rconf[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8r_f16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, G8R_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8r_f16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, G8R_LDS);
+            if (e != hipSuccess) return e;
+            rconf[dev] = true;
+        }
+        if (p.in2) hipLaunchKernelGGL(conv_gemm8r_f16<true>, dim3(p.mtiles * p.ntiles), dim3(512), G8R_LDS, s, p);
+        else hipLaunchKernelGGL(conv_gemm8r_f16<false>, dim3(p.mtiles * p.ntiles), dim3(512), G8R_LDS, s, p);
+        return hipGetLastError();
+    }
     if (p.in2) hipLaunchKernelGGL(conv_gemm8_f16<true>, dim3(p.mtiles * p.ntiles), dim3(512), lds, s, p);
     else hipLaunchKernelGGL(conv_gemm8_f16<false>, dim3(p.mtiles * p.ntiles), dim3(512), lds, s, p);
     return hipGetLastError();

@@ -2,7 +2,7 @@
 //
 // Replaces, where the feature map tiles into 16 x 32 pixel blocks, conv_igemm's 256 x 256 halo tiles for the conv2 of layer2 /
 // layer3's Bottlenecks (/root/reference/src/models/backbones/resnet.py:114-118, 132-134: 3x3, stride 1, padding 1, 128 -> 128 and
-// 256 -> 256 channels at H/8).  Those launches are bound by the bytes a tile moves through the CU's LDS-DMA path, and four fifths of
+// 256 -> 256 channels at H/8).  Those launches are bound by the bytes a tile moves into the CU (their energy: DESIGN.md section 8), and four fifths of
 // them are WEIGHTS, re-streamed once per tile: 9 taps x 4 chunks x 32 KB = 1 152 of 1 440 KB.  The weight
 // bytes of a layer are (M / BM) K N 2 whatever BN is, while the halo image makes the pixel side cheap (1.27 C bytes per pixel
 // and chunk instead of 9 C), so the tile that moves the fewest bytes per output at 65 536 accumulators is tall: 512 x 128 moves

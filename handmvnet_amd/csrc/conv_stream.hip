@@ -9,7 +9,8 @@
 // Why a second kernel.  conv_igemm gives every 256 x 256 output tile its own workgroup: per tile it streams 128 KB of weights and
 // 128 KB of pixels through the CU's vector-memory pipe for 128 KB of residual and 128 KB of output, the three phases (operands,
 // residual burst, stores) run one after the other, and the next workgroup starts cold (~4 us).  These layers do 4-16 k-steps of
-// MFMA work per tile and are bound by that pipe (~25 GB/s per CU under chip-wide load): 3.2 TB/s of algorithmic bytes.
+// MFMA work per tile and move at ~25 GB/s per CU under chip-wide load (HBM's share per CU: DESIGN.md section 8): 3.2 TB/s of
+// algorithmic bytes.
 //
 // MI355X mapping
 //   * ONE workgroup per CU for the whole launch (grid = 256).  A workgroup owns an N-slice (BN output channels) and walks the

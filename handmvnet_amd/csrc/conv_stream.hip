@@ -283,6 +283,155 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_stream_f32: the same kernel for the fp32 path's residual-bearing 1x1 convs with short reductions (Bottleneck conv3 of layer1 /
+// layer2 / layer3, K = 64 / 128 / 256: conv_igemm's `128x128,k16` and `256x128,k16,w8` families, 0.53 - 0.76 of the fp32 MFMA peak).
+// A piece is [BM pixels][32 channels] (the same 128-byte rows), an MFMA step is v_mfma_f32_32x32x2_f32 on one float per lane: a
+// 16-byte fragment feeds four steps (k = 8 q + 4 kh + e, e = 0 .. 3: conv_igemm's pairing and order), a wave's weights are
+// K / 2 registers per 32-channel block, an accumulator register group 4 q .. 4 q + 3 is four consecutive channels 8 q + 4 kh .. (no
+// row swap needed for 16-byte fp32 stores).  conv_igemm's fp32 kernels add the bias in the epilogue, (acc + bias) + residual: so does
+// this one (the bias vectors live in registers for the launch), which keeps the results bit-identical.
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES>
+__global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f32(const ConvParams p) {
+    constexpr int NWV = MW * NW, NT = 64 * NWV;
+    constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW;
+    constexpr int D = NSLOT - 1;
+    constexpr int PA = BM * 8 / NT;
+    constexpr int RB = HAS_RES ? TM * TN * 4 : 0, OS = TM * TN * 4, RS = 0;
+    constexpr int ZW = TM * TN * 4 * 1024;
+    constexpr int NFAKE = (D + NP - 1) / NP;
+    static_assert(NT == 512 && BM % 64 == 0 && PA >= 1, "eight waves; whole DMA passes per piece");
+    static_assert((NSLOT & (NSLOT - 1)) == 0 && NSLOT >= 2, "a power of two");
+    extern __shared__ __attribute__((aligned(16))) char ssm[];
+    float *sA = reinterpret_cast<float *>(ssm);                  // [NSLOT][BM][32]
+    char *zones = ssm + NSLOT * BM * 128;                         // [2][NWV][ZW]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int mw = wave / NW, nw = wave - mw * NW;
+    const int nsl = p.ntiles;
+    const int loc = (int)blockIdx.x >> 3, per_xcd = 32 / nsl;
+    const int slice = loc % nsl, stream = ((int)blockIdx.x & 7) * per_xcd + loc / nsl, nstreams = 8 * per_xcd;
+    const int ntl = p.mtiles > stream ? (p.mtiles - stream + nstreams - 1) / nstreams : 0;
+    if (ntl == 0) return;
+    const int n0 = slice * BN + nw * TN * 32;
+
+    const float *zero32 = p.zero;
+    float *trash = const_cast<float *>(p.zero) + 64 + 4 * lane;
+    const float *Ain = reinterpret_cast<const float *>(p.in);
+    const float *Rin = reinterpret_cast<const float *>(p.res);
+    float *Out = reinterpret_cast<float *>(p.out);
+
+    // ---- weights and bias -> registers, once: block b, piece j, group q: W[n0 + 32 b + l31][32 j + 8 q + 4 kh .. + 3]
+    sf32x4 wreg[TN][NP * 4], bias[TN][4];
+    {
+        const float *wb = reinterpret_cast<const float *>(p.wgt) + (size_t)(n0 + l31) * p.ldw + 4 * kh;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+#pragma unroll
+            for (int Q = 0; Q < NP * 4; ++Q) wreg[b][Q] = *reinterpret_cast<const sf32x4 *>(wb + (size_t)(32 * b) * p.ldw + 8 * Q);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias[b][g] = *reinterpret_cast<const sf32x4 *>(p.bias + n0 + 32 * b + 8 * g + 4 * kh);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const int arow = tid >> 3, kqs = (tid & 7) ^ ((tid >> 4) & 7);
+    const int fsw = (l31 >> 1) & 7;
+    auto issue_A = [&](int G) {
+        const int tt = G >= 0 ? G / NP : -1, jj = G >= 0 ? G - tt * NP : 0, slot = G & (NSLOT - 1);
+        const int mt = stream + tt * nstreams;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int m = mt * BM + i * 64 + arow;
+            const bool ok = tt >= 0 && tt < ntl && m < p.M;
+            const float *src = ok ? Ain + (size_t)m * p.lda + jj * 32 + 4 * kqs : zero32;
+            asm volatile("" : "+v"(src));
+            HMV_SGLDS16(src, sA + ((slot * BM + i * 64 + wave * 8) * 32));
+        }
+    };
+    auto issue_R = [&](int tt) {
+        if constexpr (HAS_RES) {
+            const int mt = stream + tt * nstreams;
+            char *z = zones + ((tt & 1) * NWV + wave) * ZW;
+#pragma unroll
+            for (int idx = 0; idx < RB; ++idx) {
+                const int a = idx / (4 * TN), b = (idx / 4) % TN, g = idx & 3;
+                const int m = mt * BM + (mw * TM + a) * 32 + l31;
+                const bool ok = tt >= 0 && tt < ntl && m < p.M;
+                const float *src = ok ? Rin + (size_t)m * p.ldr + n0 + 32 * b + 8 * g + 4 * kh : zero32;
+                asm volatile("" : "+v"(src));
+                HMV_SGLDS16(src, z + idx * 1024);
+            }
+        }
+    };
+#pragma unroll
+    for (int ft = -NFAKE; ft < 0; ++ft) {
+        static_for<NP>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            issue_A(ft * NP + j + D);
+            if constexpr (j == 0) issue_R(ft + 1);
+        });
+#pragma unroll
+        for (int i = 0; i < OS; ++i)
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(trash), "v"(sf32x4{0.f, 0.f, 0.f, 0.f}) : "memory");
+    }
+
+    const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    sf32x16 acc[TM][TN];
+    for (int tt = 0; tt < ntl; ++tt) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        static_for<NP>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            wait_vm<sched_after_piece(NP, D, PA, RB, RS, OS, j)>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue_A(tt * NP + j + D);
+            if constexpr (j == 0) issue_R(tt + 1);
+            const float *pa = sA + ((((tt * NP + j) & (NSLOT - 1)) * BM + mw * TM * 32 + l31) * 32);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sf32x4 px[TM];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) px[a] = *reinterpret_cast<const sf32x4 *>(pa + a * 32 * 32 + (((2 * q + kh) ^ fsw) * 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[b][4 * j + q][e], px[a][e], acc[a][b], 0, 0, 0);
+            }
+        });
+        if constexpr (HAS_RES) wait_vm<sched_after_residual(NP, PA, RB, RS, OS)>();
+        const int mt = stream + tt * nstreams;
+        const char *z = zones + ((tt & 1) * NWV + wave) * ZW + lane * 16;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int m = mt * BM + (mw * TM + a) * 32 + l31;
+            float *orow = Out + (size_t)m * p.ldc + n0 + 4 * kh;
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    sf32x4 r = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (HAS_RES) r = *reinterpret_cast<const sf32x4 *>(z + ((a * TN + b) * 4 + g) * 1024);
+                    sf32x4 t;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t[u] = fmaxf((acc[a][b][4 * g + u] + bias[b][g][u]) + r[u], lo);
+                    float *dst = m < p.M ? orow + 32 * b + 8 * g : trash;
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(t) : "memory");
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
 // ====================================================================== host side
 template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool SPREAD = false, int NT_ = 0, bool DUAL = false>
 static hipError_t launch_stream_one(ConvParams p, hipStream_t s) {
@@ -329,6 +478,16 @@ static int stream_bn(const ConvParams &p, int *bm = nullptr) {
 static int g_stream_mode = -1;
 void conv_stream_set_mode(int mode) { g_stream_mode = mode; }
 
+// fp32: residual-bearing 1x1 convs with K = 64 / 128 / 256 and Cout a multiple of 256 (64 x 256 tiles, one 32-channel block per wave)
+static bool stream32_shape(const ConvParams &p) {
+    return !p.in_f16 && !p.out_f16 && p.res && !p.res_f16 && !p.in2 && (p.Kpad == 64 || p.Kpad == 128 || p.Kpad == 256) && p.Cout % 256 == 0 &&
+           32 % (p.Cout / 256) == 0;
+}
+// ... of which the launcher takes K = 64 and 128 (layer1 / layer2 conv3: HBM-bound, 566 -> 489 us and 377 -> 359 us).  At K = 256
+// (layer3 conv3) the launch is MFMA-bound and conv_igemm's two paired 256 x 128 workgroups per CU -- one drains while the other
+// multiplies -- are 2.5 % faster than eight waves that reach the epilogue together (1 143 vs 1 172 us): op-level tests only.
+static bool stream32_rule(const ConvParams &p) { return p.Kpad <= 128; }
+
 bool conv_stream_supported(const ConvParams &p) {
     static int off = -1;   // development knob: HMV_NO_STREAM=1 keeps every conv on conv_igemm (A/B runs)
     if (off < 0) off = getenv("HMV_NO_STREAM") ? 1 : 0;
@@ -336,6 +495,18 @@ bool conv_stream_supported(const ConvParams &p) {
     if (min_env < 0) { const char *e = getenv("HMV_STREAM_MIN_TILES"); min_env = e ? atoi(e) : 4; }
     if (g_stream_mode == 0 || (g_stream_mode < 0 && off)) return false;
     const int min_tiles = g_stream_mode > 0 ? 0 : min_env;
+    if (stream32_shape(p)) {
+        static const bool off32 = getenv("HMV_NO_STREAM32") != nullptr;   // development knob (A/B runs)
+        if (off32 && g_stream_mode <= 0) return false;
+        if (p.R != 1 || p.S != 1 || p.stride != 1 || p.pad_h || p.pad_w || p.up || p.ksl > 1 || p.phases > 1) return false;
+        if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out || p.fill) return false;
+        if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
+        if (p.Cin != p.Kpad || p.K != p.Kpad) return false;
+        if ((p.lda ? p.lda : p.Cin) % 4 || (p.ldw ? p.ldw : p.Kpad) % 4 || p.ldc % 4 || p.ldr % 4) return false;
+        if (g_stream_mode > 0) return true;
+        const int streams32 = 256 / (p.Cout / 256);
+        return stream32_rule(p) && (long long)(p.M + 63) / 64 >= (long long)min_tiles * streams32;
+    }
     int bm = 0;
     const int bn = stream_bn(p, &bm);
     if (!bn || !p.in_f16 || !p.out_f16 || (p.res && !p.res_f16)) return false;
@@ -349,7 +520,32 @@ bool conv_stream_supported(const ConvParams &p) {
     return (long long)(p.M + bm - 1) / bm >= (long long)min_tiles * streams;
 }
 
+template <int NP>
+static hipError_t launch_stream32(ConvParams p, hipStream_t s) {
+    constexpr size_t lds = (size_t)4 * 64 * 128 + (size_t)2 * 8 * 2 * 4 * 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool configured[64] = {};
+    auto kern = conv_stream_f32<2, 1, 1, 8, NP, 4, true>;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!configured[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[dev] = true;
+    }
+    p.mtiles = (p.M + 63) / 64;
+    p.ntiles = p.Cout / 256;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **name) {
+    if (stream32_shape(p)) {
+        if (p.Kpad == 256) { if (name) *name = "conv_stream_f32<64x256,k256,res>"; return launch_stream32<8>(p, s); }
+        if (p.Kpad == 128) { if (name) *name = "conv_stream_f32<64x256,k128,res>"; return launch_stream32<4>(p, s); }
+        if (name) *name = "conv_stream_f32<64x256,k64,res>";
+        return launch_stream32<2>(p, s);
+    }
     // development knob (A/B runs): HMV_STREAM_VARIANT = 0 residual DMAs at step 0, 1 spread over the piece steps, 2 / 3 the same with
     // non-temporal residual loads, 4 non-temporal pixel pieces too.  Measured (profiles/r03_probe_stream_variants.txt): spreading
     // gains 3-4 % at K = 256 (four piece steps) and loses 4 % at K = 128; non-temporal loads lose 15-25 % everywhere (the next

@@ -2009,6 +2009,8 @@ int hmv_op_attention_lq(int32_t device, const float *q, int32_t q_ld, int32_t q_
     return HMV_OK;
 }
 
+static const char **g_op_kernel_name = nullptr;   // hmv_op_conv2d_sel: where the kernel family of the next hmv_op_conv2d goes
+
 int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *w_oihw,
                   const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad, const float *residual,
                   int32_t relu, float *out, void *stream) {
@@ -2041,7 +2043,7 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
         p.R = R; p.S = S; p.stride = stride; p.pad_h = pad; p.pad_w = pad;
         p.K = K; p.Kpad = Kpad; p.M = N * p.Ho * p.Wo; p.ldc = Cout; p.ldr = Cout;
         p.act = relu ? ACT_RELU : ACT_NONE; p.osy = p.osx = 1;
-        e = launch_conv(p, conv_pick_tile(p.M, Cout, K), static_cast<hipStream_t>(stream));
+        e = launch_conv(p, conv_pick_tile(p.M, Cout, K, false, residual != nullptr), static_cast<hipStream_t>(stream), g_op_kernel_name);
         if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
     }
     if (dw) (void)hipFree(dw);
@@ -2120,6 +2122,18 @@ extern "C" int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, 
         return hmv_op_conv2d(device, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad, residual, relu, out, stream);
     return op_conv2d_any("hmv_op_conv2d_ex", device, dtype, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad, residual, relu,
                          out, false, nullptr, stream);
+}
+
+extern "C" int hmv_op_conv2d_sel(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *w_oihw,
+                                 const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad,
+                                 const float *residual, int32_t relu, float *out, int32_t kernel_sel, const char **kernel_name, void *stream) {
+    if (kernel_sel < 0 || kernel_sel > 2) { g_create_err = "hmv_op_conv2d_sel: kernel_sel must be 0, 1 or 2"; return HMV_ERR_ARG; }
+    conv_stream_set_mode(kernel_sel == 0 ? -1 : kernel_sel - 1);
+    g_op_kernel_name = kernel_name;
+    const int rc = hmv_op_conv2d(device, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad, residual, relu, out, stream);
+    g_op_kernel_name = nullptr;
+    conv_stream_set_mode(-1);
+    return rc;
 }
 
 extern "C" int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *w_oihw,

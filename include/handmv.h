@@ -165,6 +165,14 @@ int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, int32_t N, 
                      const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
                      int32_t pad, const float *residual, int32_t relu, float *out, void *stream);
 
+/* hmv_op_conv2d with a kernel selector (op-level parity tests): 0 = the launcher's choice, 1 = conv_igemm only, 2 = the persistent
+ * weight-stationary kernel (conv_stream.hip, fp32 variant: residual-bearing 1x1 convs with K = 64 / 128 / 256, Cout % 256 == 0)
+ * wherever the shape has one, whatever its size.  *kernel_name (optional) receives the family that ran. */
+int hmv_op_conv2d_sel(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                      const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
+                      int32_t pad, const float *residual, int32_t relu, float *out, int32_t kernel_sel, const char **kernel_name,
+                      void *stream);
+
 /* The fp16-storage op with fp16 OUTPUT rows (what a backbone layer of the fp16 path writes): out_f16 device [N][Ho][Wo][Cout]
  * halfs.  kernel_sel: 0 = the launcher's choice, 1 = conv_igemm only, 2 = the round-3 kernels (conv_stream.hip: persistent
  * weight-stationary residual 1x1; conv_gemm8.hip: phase-interleaved 256 x 256 1x1; conv_hs.hip: halo-streaming few-channel 3x3)

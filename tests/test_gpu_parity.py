@@ -373,6 +373,47 @@ def test_tall_tile_kernel(shape):
         assert torch.equal(out.cpu()[0].view(torch.int16), a[0].view(torch.int16))
 
 
+# fp32 residual 1x1 convs on the persistent weight-stationary kernel (conv_stream_f32): K = 64 / 128 / 256, one to four channel slices,
+# ragged pixel tails, with and without ReLU, more tiles than workgroups
+STREAM32_SHAPES = [(4, 32, 32, 256, 1024, 1, 1, 0, True, True), (3, 17, 19, 128, 512, 1, 1, 0, True, True), (2, 32, 32, 64, 256, 1, 1, 0, True, False),
+                   (1, 8, 8, 256, 256, 1, 1, 0, True, True), (20, 32, 32, 256, 1024, 1, 1, 0, True, True), (40, 32, 32, 128, 512, 1, 1, 0, True, True)]
+
+
+@pytest.mark.parametrize("shape", STREAM32_SHAPES)
+def test_stream32_kernel_is_bit_identical(shape):
+    """conv_stream_f32 against conv_igemm's fp32 kernels on the same operands: same bits (the k order and pairing of the 32x32x2 MFMA
+    steps, the zero-initialised accumulator and the (acc + bias) + residual epilogue are conv_igemm's), and against torch fp64."""
+    from handmvnet_amd import _lib
+    lib = _lib.load()
+    N, H, W, Cin, Cout, k, stride, pad, use_res, relu = shape
+    g = torch.Generator().manual_seed(sum(shape[:8]))
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, H, W, Cout, generator=g)
+    dev = torch.device("cuda:0")
+    xin, rdev = x.to(dev), res.to(dev)
+    wc, bc = w.contiguous().numpy(), b.contiguous().numpy()
+    outs, names = [], []
+    for sel in (2, 1):
+        out = torch.full((N, H, W, Cout), float("nan"), device=dev)
+        kname = ctypes.c_char_p()
+        rc = lib.hmv_op_conv2d_sel(0, xin.data_ptr(), N, H, W, Cin, wc.ctypes.data_as(ctypes.c_void_p), bc.ctypes.data_as(ctypes.c_void_p),
+                                   Cout, k, k, stride, pad, rdev.data_ptr(), int(relu), out.data_ptr(), sel, ctypes.byref(kname), None)
+        assert rc == 0, lib.hmv_last_error(None)
+        outs.append(out.cpu())
+        names.append(kname.value.decode())
+    assert names[0].startswith("conv_stream_f32") and names[1].startswith("conv_igemm_f32"), names
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (names, (outs[0] - outs[1]).abs().max())
+    if N * H * W <= 8192:
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double()).permute(0, 2, 3, 1) + res.double()
+        if relu:
+            ref = ref.clamp_min(0)
+        err = (outs[0].double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 4e-6, err
+
+
 @pytest.mark.parametrize("shape", [(256, 16, 16, 160, 160, 3, 1, 1, True, True), (256, 16, 16, 160, 160, 3, 1, 1, False, False),
                                    (300, 16, 16, 80, 136, 3, 1, 1, False, True)])
 def test_wide_n_tile_192(shape):

@@ -479,14 +479,15 @@ static int g_stream_mode = -1;
 void conv_stream_set_mode(int mode) { g_stream_mode = mode; }
 
 // fp32: residual-bearing 1x1 convs with K = 64 / 128 / 256 and Cout a multiple of 256 (64 x 256 tiles, one 32-channel block per wave)
-static bool stream32_shape(const ConvParams &p) {
-    return !p.in_f16 && !p.out_f16 && p.res && !p.res_f16 && !p.in2 && (p.Kpad == 64 || p.Kpad == 128 || p.Kpad == 256) && p.Cout % 256 == 0 &&
-           32 % (p.Cout / 256) == 0;
+static int stream32_shape(const ConvParams &p) {   // 0 none; 1 residual-bearing (64 x 256 tiles); 2 the squeezing conv1 256 -> 64 (128 x 64 tiles)
+    if (p.in_f16 || p.out_f16 || p.in2) return 0;
+    if (p.res) return (!p.res_f16 && (p.Kpad == 64 || p.Kpad == 128 || p.Kpad == 256) && p.Cout % 256 == 0 && 32 % (p.Cout / 256) == 0) ? 1 : 0;
+    return (p.Kpad == 256 && p.Cout == 64) ? 2 : 0;
 }
 // ... of which the launcher takes K = 64 and 128 (layer1 / layer2 conv3: HBM-bound, 566 -> 489 us and 377 -> 359 us).  At K = 256
 // (layer3 conv3) the launch is MFMA-bound and conv_igemm's two paired 256 x 128 workgroups per CU -- one drains while the other
 // multiplies -- are 2.5 % faster than eight waves that reach the epilogue together (1 143 vs 1 172 us): op-level tests only.
-static bool stream32_rule(const ConvParams &p) { return p.Kpad <= 128; }
+static bool stream32_rule(const ConvParams &p) { return p.res ? p.Kpad <= 128 : true; }
 
 bool conv_stream_supported(const ConvParams &p) {
     static int off = -1;   // development knob: HMV_NO_STREAM=1 keeps every conv on conv_igemm (A/B runs)
@@ -502,10 +503,10 @@ bool conv_stream_supported(const ConvParams &p) {
         if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out || p.fill) return false;
         if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
         if (p.Cin != p.Kpad || p.K != p.Kpad) return false;
-        if ((p.lda ? p.lda : p.Cin) % 4 || (p.ldw ? p.ldw : p.Kpad) % 4 || p.ldc % 4 || p.ldr % 4) return false;
+        if ((p.lda ? p.lda : p.Cin) % 4 || (p.ldw ? p.ldw : p.Kpad) % 4 || p.ldc % 4 || (p.res && p.ldr % 4)) return false;
         if (g_stream_mode > 0) return true;
-        const int streams32 = 256 / (p.Cout / 256);
-        return stream32_rule(p) && (long long)(p.M + 63) / 64 >= (long long)min_tiles * streams32;
+        const int bm32 = p.res ? 64 : 128, streams32 = p.res ? 256 / (p.Cout / 256) : 256;
+        return stream32_rule(p) && (long long)(p.M + bm32 - 1) / bm32 >= (long long)min_tiles * streams32;
     }
     int bm = 0;
     const int bn = stream_bn(p, &bm);
@@ -520,12 +521,13 @@ bool conv_stream_supported(const ConvParams &p) {
     return (long long)(p.M + bm - 1) / bm >= (long long)min_tiles * streams;
 }
 
-template <int NP>
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES>
 static hipError_t launch_stream32(ConvParams p, hipStream_t s) {
-    constexpr size_t lds = (size_t)4 * 64 * 128 + (size_t)2 * 8 * 2 * 4 * 1024;
+    constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW;
+    constexpr size_t lds = (size_t)NSLOT * BM * 128 + (HAS_RES ? (size_t)2 * MW * NW * TM * TN * 4 * 1024 : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool configured[64] = {};
-    auto kern = conv_stream_f32<2, 1, 1, 8, NP, 4, true>;
+    auto kern = conv_stream_f32<TM, TN, MW, NW, NP, NSLOT, HAS_RES>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
@@ -533,18 +535,19 @@ static hipError_t launch_stream32(ConvParams p, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured[dev] = true;
     }
-    p.mtiles = (p.M + 63) / 64;
-    p.ntiles = p.Cout / 256;
+    p.mtiles = (p.M + BM - 1) / BM;
+    p.ntiles = p.Cout / BN;
     hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **name) {
-    if (stream32_shape(p)) {
-        if (p.Kpad == 256) { if (name) *name = "conv_stream_f32<64x256,k256,res>"; return launch_stream32<8>(p, s); }
-        if (p.Kpad == 128) { if (name) *name = "conv_stream_f32<64x256,k128,res>"; return launch_stream32<4>(p, s); }
+    if (const int k32 = stream32_shape(p)) {
+        if (k32 == 2) { if (name) *name = "conv_stream_f32<128x64,k256>"; return launch_stream32<1, 1, 4, 2, 8, 8, false>(p, s); }
+        if (p.Kpad == 256) { if (name) *name = "conv_stream_f32<64x256,k256,res>"; return launch_stream32<2, 1, 1, 8, 8, 4, true>(p, s); }
+        if (p.Kpad == 128) { if (name) *name = "conv_stream_f32<64x256,k128,res>"; return launch_stream32<2, 1, 1, 8, 4, 4, true>(p, s); }
         if (name) *name = "conv_stream_f32<64x256,k64,res>";
-        return launch_stream32<2>(p, s);
+        return launch_stream32<2, 1, 1, 8, 2, 4, true>(p, s);
     }
     // development knob (A/B runs): HMV_STREAM_VARIANT = 0 residual DMAs at step 0, 1 spread over the piece steps, 2 / 3 the same with
     // non-temporal residual loads, 4 non-temporal pixel pieces too.  Measured (profiles/r03_probe_stream_variants.txt): spreading

@@ -376,7 +376,9 @@ def test_tall_tile_kernel(shape):
 # fp32 residual 1x1 convs on the persistent weight-stationary kernel (conv_stream_f32): K = 64 / 128 / 256, one to four channel slices,
 # ragged pixel tails, with and without ReLU, more tiles than workgroups
 STREAM32_SHAPES = [(4, 32, 32, 256, 1024, 1, 1, 0, True, True), (3, 17, 19, 128, 512, 1, 1, 0, True, True), (2, 32, 32, 64, 256, 1, 1, 0, True, False),
-                   (1, 8, 8, 256, 256, 1, 1, 0, True, True), (20, 32, 32, 256, 1024, 1, 1, 0, True, True), (40, 32, 32, 128, 512, 1, 1, 0, True, True)]
+                   (1, 8, 8, 256, 256, 1, 1, 0, True, True), (20, 32, 32, 256, 1024, 1, 1, 0, True, True), (40, 32, 32, 128, 512, 1, 1, 0, True, True),
+                   # the squeezing conv1 256 -> 64 without a residual (128 x 64 tiles)
+                   (2, 32, 32, 256, 64, 1, 1, 0, False, True), (3, 17, 19, 256, 64, 1, 1, 0, False, False), (48, 32, 32, 256, 64, 1, 1, 0, False, True)]
 
 
 @pytest.mark.parametrize("shape", STREAM32_SHAPES)
@@ -399,7 +401,7 @@ def test_stream32_kernel_is_bit_identical(shape):
         out = torch.full((N, H, W, Cout), float("nan"), device=dev)
         kname = ctypes.c_char_p()
         rc = lib.hmv_op_conv2d_sel(0, xin.data_ptr(), N, H, W, Cin, wc.ctypes.data_as(ctypes.c_void_p), bc.ctypes.data_as(ctypes.c_void_p),
-                                   Cout, k, k, stride, pad, rdev.data_ptr(), int(relu), out.data_ptr(), sel, ctypes.byref(kname), None)
+                                   Cout, k, k, stride, pad, rdev.data_ptr() if use_res else None, int(relu), out.data_ptr(), sel, ctypes.byref(kname), None)
         assert rc == 0, lib.hmv_last_error(None)
         outs.append(out.cpu())
         names.append(kname.value.decode())
@@ -407,7 +409,9 @@ def test_stream32_kernel_is_bit_identical(shape):
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (names, (outs[0] - outs[1]).abs().max())
     if N * H * W <= 8192:
-        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double()).permute(0, 2, 3, 1) + res.double()
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double()).permute(0, 2, 3, 1)
+        if use_res:
+            ref = ref + res.double()
         if relu:
             ref = ref.clamp_min(0)
         err = (outs[0].double() - ref).abs().max().item() / ref.abs().max().item()

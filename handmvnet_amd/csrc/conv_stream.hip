@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
 // K / 2 registers per 32-channel block, an accumulator register group 4 q .. 4 q + 3 is four consecutive channels 8 q + 4 kh .. (no
 // row swap needed for 16-byte fp32 stores).  conv_igemm's fp32 kernels add the bias in the epilogue, (acc + bias) + residual: so does
 // this one (the bias vectors live in registers for the launch), which keeps the results bit-identical.
-template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES>
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool DUAL = false>
 __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f32(const ConvParams p) {
     constexpr int NWV = MW * NW, NT = 64 * NWV;
     constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW;
@@ -346,7 +346,18 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f32(co
         for (int i = 0; i < PA; ++i) {
             const int m = mt * BM + i * 64 + arow;
             const bool ok = tt >= 0 && tt < ntl && m < p.M;
-            const float *src = ok ? Ain + (size_t)m * p.lda + jj * 32 + 4 * kqs : zero32;
+            const float *src = zero32;
+            if constexpr (DUAL) {   // pieces past ksplit come from the second tensor at pixel (ho * stride2, wo * stride2)
+                if (ok && jj * 32 >= p.ksplit) {
+                    const int hw = p.Ho * p.Wo, n = m / hw, rem = m - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    src = reinterpret_cast<const float *>(p.in2) + ((size_t)(n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.lda2 +
+                          (jj * 32 - p.ksplit) + 4 * kqs;
+                } else if (ok) {
+                    src = Ain + (size_t)m * p.lda + jj * 32 + 4 * kqs;
+                }
+            } else if (ok) {
+                src = Ain + (size_t)m * p.lda + jj * 32 + 4 * kqs;
+            }
             asm volatile("" : "+v"(src));
             HMV_SGLDS16(src, sA + ((slot * BM + i * 64 + wave * 8) * 32));
         }
@@ -479,8 +490,9 @@ static int g_stream_mode = -1;
 void conv_stream_set_mode(int mode) { g_stream_mode = mode; }
 
 // fp32: residual-bearing 1x1 convs with K = 64 / 128 / 256 and Cout a multiple of 256 (64 x 256 tiles, one 32-channel block per wave)
-static int stream32_shape(const ConvParams &p) {   // 0 none; 1 residual-bearing (64 x 256 tiles); 2 the squeezing conv1 256 -> 64 (128 x 64 tiles)
-    if (p.in_f16 || p.out_f16 || p.in2) return 0;
+static int stream32_shape(const ConvParams &p) {   // 0 none; 1 residual-bearing (64 x 256 tiles); 2 the squeezing conv1 256 -> 64 (128 x 64 tiles);
+    if (p.in_f16 || p.out_f16) return 0;            // 3 conv3 + downsample of layer1.0 (64 + 64 -> 256) as one GEMM over two sources
+    if (p.in2) return (!p.res && p.Kpad == 128 && p.ksplit == 64 && p.Cout == 256 && p.lda == p.ksplit && p.lda2 % 4 == 0) ? 3 : 0;
     if (p.res) return (!p.res_f16 && (p.Kpad == 64 || p.Kpad == 128 || p.Kpad == 256) && p.Cout % 256 == 0 && 32 % (p.Cout / 256) == 0) ? 1 : 0;
     return (p.Kpad == 256 && p.Cout == 64) ? 2 : 0;
 }
@@ -502,10 +514,10 @@ bool conv_stream_supported(const ConvParams &p) {
         if (p.R != 1 || p.S != 1 || p.stride != 1 || p.pad_h || p.pad_w || p.up || p.ksl > 1 || p.phases > 1) return false;
         if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out || p.fill) return false;
         if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
-        if (p.Cin != p.Kpad || p.K != p.Kpad) return false;
+        if ((!p.in2 && p.Cin != p.Kpad) || p.K != p.Kpad) return false;
         if ((p.lda ? p.lda : p.Cin) % 4 || (p.ldw ? p.ldw : p.Kpad) % 4 || p.ldc % 4 || (p.res && p.ldr % 4)) return false;
         if (g_stream_mode > 0) return true;
-        const int bm32 = p.res ? 64 : 128, streams32 = p.res ? 256 / (p.Cout / 256) : 256;
+        const int bm32 = (p.res || p.in2) ? 64 : 128, streams32 = p.res ? 256 / (p.Cout / 256) : 256;
         return stream32_rule(p) && (long long)(p.M + bm32 - 1) / bm32 >= (long long)min_tiles * streams32;
     }
     int bm = 0;
@@ -521,13 +533,13 @@ bool conv_stream_supported(const ConvParams &p) {
     return (long long)(p.M + bm - 1) / bm >= (long long)min_tiles * streams;
 }
 
-template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES>
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool DUAL = false>
 static hipError_t launch_stream32(ConvParams p, hipStream_t s) {
     constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW;
     constexpr size_t lds = (size_t)NSLOT * BM * 128 + (HAS_RES ? (size_t)2 * MW * NW * TM * TN * 4 * 1024 : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool configured[64] = {};
-    auto kern = conv_stream_f32<TM, TN, MW, NW, NP, NSLOT, HAS_RES>;
+    auto kern = conv_stream_f32<TM, TN, MW, NW, NP, NSLOT, HAS_RES, DUAL>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
@@ -544,6 +556,7 @@ static hipError_t launch_stream32(ConvParams p, hipStream_t s) {
 hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **name) {
     if (const int k32 = stream32_shape(p)) {
         if (k32 == 2) { if (name) *name = "conv_stream_f32<128x64,k256>"; return launch_stream32<1, 1, 4, 2, 8, 8, false>(p, s); }
+        if (k32 == 3) { if (name) *name = "conv_stream_f32<64x256,k128,dual>"; return launch_stream32<2, 1, 1, 8, 4, 8, false, true>(p, s); }
         if (p.Kpad == 256) { if (name) *name = "conv_stream_f32<64x256,k256,res>"; return launch_stream32<2, 1, 1, 8, 8, 4, true>(p, s); }
         if (p.Kpad == 128) { if (name) *name = "conv_stream_f32<64x256,k128,res>"; return launch_stream32<2, 1, 1, 8, 4, 4, true>(p, s); }
         if (name) *name = "conv_stream_f32<64x256,k64,res>";

@@ -1373,6 +1373,8 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     if ((p.cwrap || p.res_split || p.out_split || p.acc_shift) &&
         (!p.in_f16 || p.rd_cout || (p.ldc & 3) || (p.res && (p.ldr & 3)) || p.act == ACT_GELU || p.act == ACT_LEAKY))
         return hipErrorInvalidValue;
+    // row-decomposed fp32 convs over many pixels (HRNet-w40's 40- / 80-channel branches): the persistent weight-stationary kernel
+    if (p.rd_cout && !generic && conv_rds_supported(p)) return launch_conv_rds(p, s, name);
     if (p.rd_cout) {   // row-decomposed 3x3 (see conv_igemm): the caller passes the 3x1 GEMM (R = 3, S = 1, Cout = 3 * rd_cout)
         if (generic || p.R != 3 || p.S != 1 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 0 || p.Cout != 3 * p.rd_cout || p.Cout > 256 ||
             (p.rd_cout & 3) || (p.ldc & 3) || (p.res && (p.ldr & 3)) || 128 % p.Wo != 0 || p.Ho != p.H || p.Wo != p.W)
@@ -1435,6 +1437,8 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         }
         if (tile == TILE_128x128) { HMV_PARTN(128, 128, 2, 2) }
         if (tile == TILE_256x128) { HMV_PARTN(256, 128, 4, 2) }
+        // (an 8 x 1 wave layout -- every wave 32 pixels x all columns, so that the five real blocks of a 160-column layer load all SIMDs
+        // alike -- cannot stage its epilogue: eight 32-row blocks x 260 columns are 266 KB of LDS)
         if (tile == TILE_256x256) { HMV_PARTN(256, 256, 2, 4) }
 #undef HMV_PARTN
     }

@@ -2124,6 +2124,53 @@ extern "C" int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, 
                          out, false, nullptr, stream);
 }
 
+// One fp32 3x3 stride-1 pad-1 conv C -> C in the ROW-DECOMPOSED packing (Loader::conv, rd) through Runner::conv: what HRNet-w40's 40- /
+// 80-channel branches run.  kernel_sel: 0 the launcher's choice, 1 conv_igemm's row-decomposed tiles, 2 conv_rds.hip whatever the size
+extern "C" int hmv_op_conv2d_rd(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t C, const float *w_oihw,
+                                const float *bias_host, const float *residual, int32_t relu, float *out, int32_t kernel_sel,
+                                const char **kernel_name, void *stream) {
+    if (!in || !w_oihw || !out || C % 4 != 0 || 3 * C > 256 || C % 32 == 0 || W <= 0 || 128 % W != 0 || kernel_sel < 0 || kernel_sel > 2) {
+        g_create_err = "hmv_op_conv2d_rd: C % 4 == 0, C % 32 != 0, 3 C <= 256, 128 % W == 0, kernel_sel 0 .. 2";
+        return HMV_ERR_ARG;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hmv_engine eng;
+    eng.cfg.device = device;
+    HostTensor wt;
+    wt.shape = {C, C, 3, 3};
+    wt.data.assign(w_oihw, w_oihw + (size_t)C * C * 9);
+    eng.host["w"] = wt;
+    // (the row-decomposed packing takes its shift from a BatchNorm: an identity BN whose shift is the bias)
+    HostTensor g1, b1, m0, v1;
+    g1.shape = b1.shape = m0.shape = v1.shape = {C};
+    g1.data.assign(C, 1.f); m0.data.assign(C, 0.f);
+    v1.data.assign(C, 1.f - 1e-5f);   // scale = 1 / sqrt(var + eps) == 1 to fp32 rounding
+    b1.data.assign(C, 0.f);
+    if (bias_host) b1.data.assign(bias_host, bias_host + C);
+    eng.host["bn.weight"] = g1; eng.host["bn.bias"] = b1; eng.host["bn.running_mean"] = m0; eng.host["bn.running_var"] = v1;
+    Loader L{&eng};
+    Layer layer;
+    L.conv(layer, "op", "w", "", "bn", C, C, 3, 3, 0, false, true);
+    int rc = L.rc;
+    hipError_t e = hipSuccess;
+    if (rc == HMV_OK && !layer.rd_cout) { eng.err = "the layer was not packed row-decomposed"; rc = HMV_ERR_ARG; }
+    if (rc == HMV_OK) {
+        conv_rds_set_mode(kernel_sel == 0 ? -1 : kernel_sel - 1);
+        Arena dummy;
+        Runner Rn{&eng, s, false, HMV_OK, dummy};
+        Rn.kernel_name = kernel_name;
+        Rn.conv(layer, in, N, H, W, 1, 1, 1, out, C, residual, C, relu ? ACT_RELU : ACT_NONE, H, W, 0, 0, 0, 0, 0, false);
+        rc = Rn.rc;
+        conv_rds_set_mode(-1);
+        if (rc == HMV_OK) e = hipStreamSynchronize(s);
+    }
+    for (void *ptr : eng.dev_allocs) (void)hipFree(ptr);
+    if (rc != HMV_OK) { g_create_err = std::string("hmv_op_conv2d_rd: ") + eng.err; return rc; }
+    if (e != hipSuccess) { g_create_err = std::string("hmv_op_conv2d_rd: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
+    return HMV_OK;
+}
+
 extern "C" int hmv_op_conv2d_sel(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *w_oihw,
                                  const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad,
                                  const float *residual, int32_t relu, float *out, int32_t kernel_sel, const char **kernel_name, void *stream) {

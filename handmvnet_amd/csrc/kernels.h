@@ -155,6 +155,11 @@ hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name);
 bool conv_hs_supported(const ConvParams &p);
 void conv_hs_set_mode(int mode);
 hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name);
+// conv_rds.hip: fp32 row-decomposed 3x3 convs (HRNet-w40's 40- / 80-channel branches) on the persistent weight-stationary
+// structure; bit-identical to conv_igemm's row-decomposed tiles
+bool conv_rds_supported(const ConvParams &p);
+void conv_rds_set_mode(int mode);   // -1 launch_conv's rule, 0 never, 1 whenever supported (op-level tests)
+hipError_t launch_conv_rds(const ConvParams &p, hipStream_t s, const char **name);
 // conv_ht.hip: fp16 3x3 stride-1 convs on tall 512-pixel x 128-channel tiles (K order (32-channel chunk, r, s, c % 32)); the
 // shape rule is asked at weight-packing time, so a layer it takes runs there at every batch size
 bool conv_ht_shape_ok(int R, int S, int stride, int pad, int Cin, int Cout, int H, int W);

@@ -165,6 +165,14 @@ int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, int32_t N, 
                      const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
                      int32_t pad, const float *residual, int32_t relu, float *out, void *stream);
 
+/* One fp32 3x3 stride-1 pad-1 conv C -> C (+ bias, optional residual / ReLU) in the engine's ROW-DECOMPOSED packing -- what HRNet-w40's
+ * 40- and 80-channel branch convs run (hrnet.py:96-221).  C % 4 == 0, C % 32 != 0, 3 C <= 256, 128 % W == 0.  kernel_sel: 0 = the
+ * launcher's choice, 1 = conv_igemm's row-decomposed tiles, 2 = the persistent weight-stationary kernel (conv_rds.hip; C = 40 / 80,
+ * 64 % W == 0) whatever the size.  *kernel_name (optional) receives the family that ran. */
+int hmv_op_conv2d_rd(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t C, const float *weight_oihw_host,
+                     const float *bias_host, const float *residual, int32_t relu, float *out, int32_t kernel_sel,
+                     const char **kernel_name, void *stream);
+
 /* hmv_op_conv2d with a kernel selector (op-level parity tests): 0 = the launcher's choice, 1 = conv_igemm only, 2 = the persistent
  * weight-stationary kernel (conv_stream.hip, fp32 variant: residual-bearing 1x1 convs with K = 64 / 128 / 256, Cout % 256 == 0)
  * wherever the shape has one, whatever its size.  *kernel_name (optional) receives the family that ran. */

@@ -418,6 +418,49 @@ def test_stream32_kernel_is_bit_identical(shape):
         assert err < 4e-6, err
 
 
+# row-decomposed fp32 3x3 convs on the persistent kernel (conv_rds.hip): (images, H, W, C, residual, relu); one and two image rows per
+# 64-pixel tile, fewer tiles than workgroups and more, a ragged last round
+RDS_SHAPES = [(2, 64, 64, 40, True, True), (1, 64, 64, 40, False, False), (3, 32, 32, 80, True, True), (5, 32, 32, 80, False, True),
+              (24, 64, 64, 40, True, True), (70, 32, 32, 80, True, False), (3, 16, 16, 40, True, True)]
+
+
+@pytest.mark.parametrize("shape", RDS_SHAPES)
+def test_rds_kernel_is_bit_identical(shape):
+    """conv_rds_f32 against conv_igemm's row-decomposed tiles on the same packed operands: same bits (MFMA pairing and order, the
+    epilogue's (((bias + G_0) + G_1) + G_2) + residual), and against torch fp64."""
+    from handmvnet_amd import _lib
+    lib = _lib.load()
+    N, H, W, C, use_res, relu = shape
+    g = torch.Generator().manual_seed(sum(shape[:4]) + 7)
+    x = torch.randn(N, H, W, C, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(C, generator=g)
+    res = torch.randn(N, H, W, C, generator=g)
+    dev = torch.device("cuda:0")
+    xin, rdev = x.to(dev), res.to(dev)
+    wc, bc = w.contiguous().numpy(), b.contiguous().numpy()
+    outs, names = [], []
+    for sel in (2, 1):
+        out = torch.full((N, H, W, C), float("nan"), device=dev)
+        kname = ctypes.c_char_p()
+        rc = lib.hmv_op_conv2d_rd(0, xin.data_ptr(), N, H, W, C, wc.ctypes.data_as(ctypes.c_void_p), bc.ctypes.data_as(ctypes.c_void_p),
+                                  rdev.data_ptr() if use_res else None, int(relu), out.data_ptr(), sel, ctypes.byref(kname), None)
+        assert rc == 0, lib.hmv_last_error(None)
+        outs.append(out.cpu())
+        names.append(kname.value.decode())
+    assert names[0].startswith("conv_rds_f32") and names[1].startswith("conv_igemm_f32") and "rowsum" in names[1], names
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (names, (outs[0] - outs[1]).abs().max())
+    if N * H * W <= 16384:
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        if use_res:
+            ref = ref + res.double()
+        if relu:
+            ref = ref.clamp_min(0)
+        err = (outs[0].double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-5, err
+
+
 @pytest.mark.parametrize("shape", [(256, 16, 16, 160, 160, 3, 1, 1, True, True), (256, 16, 16, 160, 160, 3, 1, 1, False, False),
                                    (300, 16, 16, 80, 136, 3, 1, 1, False, True)])
 def test_wide_n_tile_192(shape):

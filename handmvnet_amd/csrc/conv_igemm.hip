@@ -1243,6 +1243,14 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
     // channel counts that are not multiples of 128 (HRNet-w40: 160, 320), measured with tools/hr_sweep.py: one 256-wide
     // N-tile with its all-padding blocks skipped beats two 128-wide tiles whose second one is mostly DMA latency;
     // 64-wide tiles beat 128-wide ones when the last 128-wide tile would be at most half real.
+    // round 3, fp32, re-measured per layer on HRNet-w40 (tools/gpu_r03_hr320.sh: forced-tile runs of bench.py --workload hr40
+    // --per-layer): 80 and 160 output channels are whole multiples of NO wider tile, and 32-wide tiles spend nothing on padding
+    // columns -- 160-channel 3x3 convs 303 -> 282 us, the 80- / 160-channel fuse layers 131 -> 96, 224 -> 156, 242 -> 212 us (the
+    // one long-reduction case, 3x3 256 -> 80, keeps its 256 x 128 tile: 1 014 vs 1 057 us); 320 channels over 16 384 pixels run as
+    // 640 tiles of 128 x 64 -- 2.5 per CU, a ragged single round -- or 1 280 tiles of 64 x 64, five per CU: 308 -> 268 us
+    if (!f16 && Cout > 64 && Cout <= 192 && Cout % 64 != 0 && M >= 16384 && K < 2048) return TILE_128x32;
+    if (!f16 && Cout > 256 && Cout % 128 != 0 && Cout % 128 <= 64 && M >= 16384 && (long long)((M + 127) / 128) * ((Cout + 63) / 64) < 1024)
+        return TILE_64x64;
     if (Cout > 128 && Cout <= 192 && M >= 16384) return (M + 255) / 256 >= 256 ? TILE_256x256 : TILE_128x64;
     if (Cout > 256 && M >= 16384 && Cout % 128 != 0 && Cout % 128 <= 64) return TILE_128x64;
     if (Cout > 128 && (long long)((M + 255) / 256) * ((Cout + 255) / 256) >= 512) return TILE_256x256;

@@ -1257,7 +1257,14 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
     if (Cout > 64 && (long long)((M + 255) / 256) * ((Cout + 127) / 128) >= 512) return TILE_256x128;
     // small problems (few frames, or the token GEMMs of the fusion transformer): 64x64 tiles give 4x the
     // workgroups and 4x shorter k-steps, which is what matters when the 128-wide tiling cannot fill 256 CUs
+    // (long fp32 reductions whose 128 x 64 tiling still gives every CU a tile: layer3's 3x3 convs of one 8-view sample, 93.5 -> 90 us)
+    if (!f16 && K >= 1024 && Cout >= 256 && (long long)((M + 127) / 128) * ((Cout + 127) / 128) < 256 &&
+        (long long)((M + 127) / 128) * ((Cout + 63) / 64) >= 256)
+        return TILE_128x64;
     if (Cout > 32 && (long long)((M + 127) / 128) * ((Cout + 127) / 128) < 256) return TILE_64x64;
+    // ... and the expanding 1x1 convs of a single multi-view sample (fp32 Bottleneck conv3, K <= 256: little MFMA work per 128 x 128
+    // tile, so 4x the workgroups win up to 1 024 of the big tiles: batch-1 layer3 conv3 50 -> 46 us, layer1 conv3 26 -> 21 us)
+    if (!f16 && K <= 256 && Cout >= 256 && (long long)((M + 127) / 128) * ((Cout + 127) / 128) < 1024) return TILE_64x64;
     if (Cout > 64) return TILE_128x128;
     if (Cout > 32) return TILE_128x64;
     return TILE_128x32;

@@ -291,8 +291,10 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
 // K / 2 registers per 32-channel block, an accumulator register group 4 q .. 4 q + 3 is four consecutive channels 8 q + 4 kh .. (no
 // row swap needed for 16-byte fp32 stores).  conv_igemm's fp32 kernels add the bias in the epilogue, (acc + bias) + residual: so does
 // this one (the bias vectors live in registers for the launch), which keeps the results bit-identical.
-template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool DUAL = false>
-__global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f32(const ConvParams p) {
+// HALF: a FOUR-wave workgroup (two per CU, grid 512) with ONE wave-private residual zone, filled for the tile's own epilogue at its first
+// piece step: the MFMA-bound K = 256 case, where the two workgroups of a CU drift apart and one's epilogue runs under the other's MFMAs
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool DUAL = false, bool HALF = false>
+__global__ __launch_bounds__(64 * MW *NW, 2) void conv_stream_f32(const ConvParams p) {
     constexpr int NWV = MW * NW, NT = 64 * NWV;
     constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW;
     constexpr int D = NSLOT - 1;
@@ -300,18 +302,19 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f32(co
     constexpr int RB = HAS_RES ? TM * TN * 4 : 0, OS = TM * TN * 4, RS = 0;
     constexpr int ZW = TM * TN * 4 * 1024;
     constexpr int NFAKE = (D + NP - 1) / NP;
-    static_assert(NT == 512 && BM % 64 == 0 && PA >= 1, "eight waves; whole DMA passes per piece");
+    constexpr int RPP = NT / 8;                  // piece rows per DMA pass
+    static_assert((NT == 512 || (HALF && NT == 256)) && BM % RPP == 0 && PA >= 1 && (!HALF || (HAS_RES && !DUAL)), "whole DMA passes per piece");
     static_assert((NSLOT & (NSLOT - 1)) == 0 && NSLOT >= 2, "a power of two");
     extern __shared__ __attribute__((aligned(16))) char ssm[];
     float *sA = reinterpret_cast<float *>(ssm);                  // [NSLOT][BM][32]
-    char *zones = ssm + NSLOT * BM * 128;                         // [2][NWV][ZW]
+    char *zones = ssm + NSLOT * BM * 128;                         // [2][NWV][ZW]  (HALF: [NWV][ZW])
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
     const int mw = wave / NW, nw = wave - mw * NW;
     const int nsl = p.ntiles;
-    const int loc = (int)blockIdx.x >> 3, per_xcd = 32 / nsl;
+    const int loc = (int)blockIdx.x >> 3, per_xcd = ((int)gridDim.x >> 3) / nsl;
     const int slice = loc % nsl, stream = ((int)blockIdx.x & 7) * per_xcd + loc / nsl, nstreams = 8 * per_xcd;
     const int ntl = p.mtiles > stream ? (p.mtiles - stream + nstreams - 1) / nstreams : 0;
     if (ntl == 0) return;
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f32(co
         const int mt = stream + tt * nstreams;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int m = mt * BM + i * 64 + arow;
+            const int m = mt * BM + i * RPP + arow;
             const bool ok = tt >= 0 && tt < ntl && m < p.M;
             const float *src = zero32;
             if constexpr (DUAL) {   // pieces past ksplit come from the second tensor at pixel (ho * stride2, wo * stride2)
@@ -359,13 +362,13 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f32(co
                 src = Ain + (size_t)m * p.lda + jj * 32 + 4 * kqs;
             }
             asm volatile("" : "+v"(src));
-            HMV_SGLDS16(src, sA + ((slot * BM + i * 64 + wave * 8) * 32));
+            HMV_SGLDS16(src, sA + ((slot * BM + i * RPP + wave * 8) * 32));
         }
     };
     auto issue_R = [&](int tt) {
         if constexpr (HAS_RES) {
             const int mt = stream + tt * nstreams;
-            char *z = zones + ((tt & 1) * NWV + wave) * ZW;
+            char *z = zones + ((HALF ? 0 : (tt & 1)) * NWV + wave) * ZW;
 #pragma unroll
             for (int idx = 0; idx < RB; ++idx) {
                 const int a = idx / (4 * TN), b = (idx / 4) % TN, g = idx & 3;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f32(co
         static_for<NP>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             issue_A(ft * NP + j + D);
-            if constexpr (j == 0) issue_R(ft + 1);
+            if constexpr (j == 0) issue_R(HALF ? ft : ft + 1);
         });
 #pragma unroll
         for (int i = 0; i < OS; ++i)
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f32(co
             wait_vm<sched_after_piece(NP, D, PA, RB, RS, OS, j)>();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             issue_A(tt * NP + j + D);
-            if constexpr (j == 0) issue_R(tt + 1);
+            if constexpr (j == 0) issue_R(HALF ? tt : tt + 1);   // (HALF: this wave's epilogue reads of the previous tile are behind the lgkmcnt(0) above)
             const float *pa = sA + ((((tt * NP + j) & (NSLOT - 1)) * BM + mw * TM * 32 + l31) * 32);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -419,9 +422,9 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f32(co
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[b][4 * j + q][e], px[a][e], acc[a][b], 0, 0, 0);
             }
         });
-        if constexpr (HAS_RES) wait_vm<sched_after_residual(NP, PA, RB, RS, OS)>();
+        if constexpr (HAS_RES) wait_vm<HALF ? (NP - 1) * PA : sched_after_residual(NP, PA, RB, RS, OS)>();   // HALF: the piece DMAs of steps 1 .. NP - 1 followed it
         const int mt = stream + tt * nstreams;
-        const char *z = zones + ((tt & 1) * NWV + wave) * ZW + lane * 16;
+        const char *z = zones + ((HALF ? 0 : (tt & 1)) * NWV + wave) * ZW + lane * 16;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int m = mt * BM + (mw * TM + a) * 32 + l31;
@@ -496,10 +499,14 @@ static int stream32_shape(const ConvParams &p) {   // 0 none; 1 residual-bearing
     if (p.res) return (!p.res_f16 && (p.Kpad == 64 || p.Kpad == 128 || p.Kpad == 256) && p.Cout % 256 == 0 && 32 % (p.Cout / 256) == 0) ? 1 : 0;
     return (p.Kpad == 256 && p.Cout == 64) ? 2 : 0;
 }
-// ... of which the launcher takes K = 64 and 128 (layer1 / layer2 conv3: HBM-bound, 566 -> 489 us and 377 -> 359 us).  At K = 256
-// (layer3 conv3) the launch is MFMA-bound and conv_igemm's two paired 256 x 128 workgroups per CU -- one drains while the other
-// multiplies -- are 2.5 % faster than eight waves that reach the epilogue together (1 143 vs 1 172 us): op-level tests only.
-static bool stream32_rule(const ConvParams &p) { return p.res ? p.Kpad <= 128 : true; }
+// ... all of which the launcher takes.  K = 64 and 128 (layer1 / layer2 conv3) are HBM-bound: 566 -> 489 us and 377 -> 359 us.  K = 256
+// (layer3 conv3) is MFMA-bound: as eight waves that reach their epilogue together it is 2.5 % SLOWER than conv_igemm's two paired
+// 256 x 128 workgroups per CU (1 172 vs 1 143 us); as two four-wave workgroups per CU on 64 x 128 tiles (HALF) the epilogues overlap the
+// other workgroup's MFMAs again and it is 1.8 % faster (1 125 us).
+static bool stream32_rule(const ConvParams &p) {
+    static const bool no256 = getenv("HMV_NO_STREAM32_K256") != nullptr;   // development knob (A/B runs)
+    return p.res ? (p.Kpad <= 128 || (!no256 && p.Cout % 128 == 0 && 64 % (p.Cout / 128) == 0)) : true;
+}
 
 bool conv_stream_supported(const ConvParams &p) {
     static int off = -1;   // development knob: HMV_NO_STREAM=1 keeps every conv on conv_igemm (A/B runs)
@@ -533,13 +540,13 @@ bool conv_stream_supported(const ConvParams &p) {
     return (long long)(p.M + bm - 1) / bm >= (long long)min_tiles * streams;
 }
 
-template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool DUAL = false>
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool DUAL = false, bool HALF = false>
 static hipError_t launch_stream32(ConvParams p, hipStream_t s) {
     constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW;
-    constexpr size_t lds = (size_t)NSLOT * BM * 128 + (HAS_RES ? (size_t)2 * MW * NW * TM * TN * 4 * 1024 : 0);
-    static_assert(lds <= 160 * 1024, "LDS budget");
+    constexpr size_t lds = (size_t)NSLOT * BM * 128 + (HAS_RES ? (size_t)(HALF ? 1 : 2) * MW * NW * TM * TN * 4 * 1024 : 0);
+    static_assert(lds * (HALF ? 2 : 1) <= 160 * 1024, "LDS budget");
     static bool configured[64] = {};
-    auto kern = conv_stream_f32<TM, TN, MW, NW, NP, NSLOT, HAS_RES, DUAL>;
+    auto kern = conv_stream_f32<TM, TN, MW, NW, NP, NSLOT, HAS_RES, DUAL, HALF>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
@@ -549,7 +556,7 @@ static hipError_t launch_stream32(ConvParams p, hipStream_t s) {
     }
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = p.Cout / BN;
-    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(HALF ? 512 : 256), dim3(64 * MW * NW), lds, s, p);
     return hipGetLastError();
 }
 
@@ -557,6 +564,10 @@ hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **n
     if (const int k32 = stream32_shape(p)) {
         if (k32 == 2) { if (name) *name = "conv_stream_f32<128x64,k256>"; return launch_stream32<1, 1, 4, 2, 8, 8, false>(p, s); }
         if (k32 == 3) { if (name) *name = "conv_stream_f32<64x256,k128,dual>"; return launch_stream32<2, 1, 1, 8, 4, 8, false, true>(p, s); }
+        if (p.Kpad == 256 && p.Cout % 128 == 0 && 64 % (p.Cout / 128) == 0) {   // four-wave workgroups, two per CU, 64 x 128 tiles
+            if (name) *name = "conv_stream_f32<64x128,k256,res>";
+            return launch_stream32<2, 1, 1, 4, 8, 4, true, false, true>(p, s);
+        }
         if (p.Kpad == 256) { if (name) *name = "conv_stream_f32<64x256,k256,res>"; return launch_stream32<2, 1, 1, 8, 8, 4, true>(p, s); }
         if (p.Kpad == 128) { if (name) *name = "conv_stream_f32<64x256,k128,res>"; return launch_stream32<2, 1, 1, 8, 4, 4, true>(p, s); }
         if (name) *name = "conv_stream_f32<64x256,k64,res>";

@@ -91,9 +91,12 @@ def test_pmc_summary_names_the_round3_kernels_like_the_engine_does():
     assert ps.family("void hmv::conv_hs_f16<3, 3, 5, 2, 1, 4, 2, 3, true>(hmv::ConvParams)") == "conv_hs_f16<3x3,40->40,res>"
     assert ps.family("void hmv::conv_hs_f16<4, 4, 2, 2, 1, 4, 2, 4, false>(hmv::ConvParams)") == "conv_hs_f16<4x4,16->64>"
     assert ps.family("hmv::conv_ht_f16(hmv::ConvParams)") == "conv_ht_f16<512x128,3x3>"
-    assert ps.family("void hmv::conv_stream_f32<2, 1, 1, 8, 2, 4, true, false>(hmv::ConvParams)") == "conv_stream_f32<64x256,k64,res>"
-    assert ps.family("void hmv::conv_stream_f32<2, 1, 1, 8, 4, 8, false, true>(hmv::ConvParams)") == "conv_stream_f32<64x256,k128,dual>"
-    assert ps.family("void hmv::conv_stream_f32<1, 1, 4, 2, 8, 8, false, false>(hmv::ConvParams)") == "conv_stream_f32<128x64,k256>"
+    assert ps.family("void hmv::conv_stream_f32<2, 1, 1, 8, 2, 4, true, false, false>(hmv::ConvParams)") == "conv_stream_f32<64x256,k64,res>"
+    assert ps.family("void hmv::conv_stream_f32<2, 1, 1, 8, 4, 8, false, true, false>(hmv::ConvParams)") == "conv_stream_f32<64x256,k128,dual>"
+    assert ps.family("void hmv::conv_stream_f32<1, 1, 4, 2, 8, 8, false, false, false>(hmv::ConvParams)") == "conv_stream_f32<128x64,k256>"
+    assert ps.family("void hmv::conv_stream_f32<2, 1, 1, 4, 8, 4, true, false, true>(hmv::ConvParams)") == "conv_stream_f32<64x128,k256,res>"
+    assert ps.family("void hmv::conv_rds_f32<40, true, 4>(hmv::ConvParams)") == "conv_rds_f32<3x3,40->40,res>"
+    assert ps.family("void hmv::conv_rds_f32<80, false, 8>(hmv::ConvParams)") == "conv_rds_f32<3x3,80->80>"
     assert ps.family("void hmv::conv_hs_f16<3, 3, 10, 2, 1, 2, 3, 3, true>(hmv::ConvParams)") == "conv_hs_f16<3x3,80->80,res>"
     assert ps.family("void hmv::conv_igemm<float, 256, 256, 2, 4, 0, false, 32, false, false, false, false>(hmv::ConvParams)") == "conv_igemm_f32<256x256,taps>"
     assert ps.family("void hmv::conv_igemm<float, 256, 128, 4, 2, 1, false, 16, false, false, false, false>(hmv::ConvParams)") == "conv_igemm_f32<256x128,k16,1x1>"

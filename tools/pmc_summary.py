@@ -46,8 +46,8 @@ def family(name: str) -> str:
         targs = name[name.index("<") + 1:name.index(">")].split(", ")
         tail = ",res>" if m.group(6) == "true" else (",dual>" if len(targs) >= 10 and targs[9] == "true" else ">")
         return f"conv_stream_f16<{32 * tm * mw}x{32 * tn * nw},k{64 * np_}" + tail
-    # conv_stream_f32<TM, TN, MW, NW, NP, NSLOT, HAS_RES, DUAL>: 32-channel pieces
-    m = re.match(r"(?:void )?(?:hmv::)?conv_stream_f32<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, (true|false)(?:, (true|false))?>", name)
+    # conv_stream_f32<TM, TN, MW, NW, NP, NSLOT, HAS_RES, DUAL, HALF>: 32-channel pieces
+    m = re.match(r"(?:void )?(?:hmv::)?conv_stream_f32<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, (true|false)(?:, (true|false))?(?:, (?:true|false))?>", name)
     if m:
         tm, tn, mw, nw, np_ = (int(m.group(i)) for i in range(1, 6))
         tail = ",res>" if m.group(6) == "true" else (",dual>" if m.group(7) == "true" else ">")
@@ -58,6 +58,9 @@ def family(name: str) -> str:
         r_, s_, cpp, tn, nw = (int(m.group(i)) for i in range(1, 6))
         cout = 40 if cpp == 5 else (80 if cpp == 10 else 32 * tn * nw)   # 40- / 80-channel layers run on 64 / 96 weight rows
         return f"conv_hs_f16<{r_}x{s_},{8 * cpp}->{cout}" + (",res>" if m.group(6) == "true" else ">")
+    m = re.match(r"(?:void )?(?:hmv::)?conv_rds_f32<(\d+), (true|false), \d+>", name)
+    if m:
+        return f"conv_rds_f32<3x3,{m.group(1)}->{m.group(1)}" + (",res>" if m.group(2) == "true" else ">")
     if re.match(r"(?:void )?(?:hmv::)?conv_ht_f16\b", name) or name.startswith("_ZN3hmv11conv_ht_f16"):
         return "conv_ht_f16<512x128,3x3>"
     m = re.match(r"(?:void )?(?:hmv::)?conv_gemm8_f16<(true|false)>", name)

@@ -1262,7 +1262,7 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
     // small problems (few frames, or the token GEMMs of the fusion transformer): 64x64 tiles give 4x the
     // workgroups and 4x shorter k-steps, which is what matters when the 128-wide tiling cannot fill 256 CUs
     // (long fp32 reductions whose 128 x 64 tiling still gives every CU a tile: layer3's 3x3 convs of one 8-view sample, 93.5 -> 90 us)
-    if (!f16 && K >= 1024 && Cout >= 256 && (long long)((M + 127) / 128) * ((Cout + 127) / 128) < 256 &&
+    if (!f16 && K >= 2048 && Cout >= 256 && (long long)((M + 127) / 128) * ((Cout + 127) / 128) < 256 &&
         (long long)((M + 127) / 128) * ((Cout + 63) / 64) >= 256)
         return TILE_128x64;
     if (Cout > 32 && (long long)((M + 127) / 128) * ((Cout + 127) / 128) < 256) return TILE_64x64;

@@ -1242,7 +1242,7 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
         return TILE_256x128_K16W8;
     // ... and the squeezing conv1 of layer2 (256 / 512 -> 128, no residual): one N-tile, eight k-steps of 32 or sixteen -- the same
     // short-tile regime; forced-tile runs of bench.py --per-layer (round 3): 692 -> 595 us and 300 -> 276 us
-    if (!no_w8 && !f16 && !has_res && K >= 256 && K <= 512 && Cout > 64 && Cout <= 128 && (long long)((M + 255) / 256) >= 1024)
+    if (!no_w8 && !f16 && !has_res && K >= 256 && K <= 512 && Cout == 128 && (long long)((M + 255) / 256) >= 1024)
         return TILE_256x128_K16W8;
     // channel counts that are not multiples of 128 (HRNet-w40: 160, 320), measured with tools/hr_sweep.py: one 256-wide
     // N-tile with its all-padding blocks skipped beats two 128-wide tiles whose second one is mostly DMA latency;

@@ -484,6 +484,20 @@ extern "C" {
 
 const char *hmv_version(void) { return "handmv-mi355x 0.1 (gfx950, fp32 MFMA)"; }
 
+// The tile conv_igemm's launcher rule gives a conv / GEMM of M output pixels, Cout channels and reduction length K ("256x256", "128x32",
+// "256x128,k16,w8" ...): host logic only, no GPU call -- the CPU tests pin the rules that were measured on the hardware.
+const char *hmv_tile_rule(int32_t M, int32_t Cout, int32_t K, int32_t f16, int32_t has_residual) {
+    const ConvTile t = conv_pick_tile(M, Cout, K, f16 != 0, has_residual != 0);
+    const char *n = f16 ? conv_tile_name_f16(t, 0) : conv_tile_name(t, 0);   // "conv_igemm_f32<256x256,taps>"
+    static thread_local char buf[64];
+    const char *lt = strchr(n, '<'), *comma = lt ? strrchr(n, ',') : nullptr;
+    if (!lt || !comma || comma < lt) return n;
+    const size_t len = (size_t)(comma - lt - 1) < sizeof(buf) - 1 ? (size_t)(comma - lt - 1) : sizeof(buf) - 1;
+    memcpy(buf, lt + 1, len);
+    buf[len] = 0;
+    return buf;
+}
+
 const char *hmv_last_error(hmv_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 int hmv_create(const hmv_config *cfg, hmv_handle *out) {

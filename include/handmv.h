@@ -253,6 +253,10 @@ int hmv_pose_metrics(int32_t device, const float *pred, const float *target, int
 
 const char *hmv_version(void);
 
+/* The tile shape the general conv / GEMM kernel's launcher rule picks for M output pixels, Cout channels, reduction length K
+ * (e.g. "256x256", "128x32", "256x128,k16,w8"); host logic only, valid until the calling thread's next call. */
+const char *hmv_tile_rule(int32_t M, int32_t Cout, int32_t K, int32_t f16, int32_t has_residual);
+
 #ifdef __cplusplus
 }
 #endif

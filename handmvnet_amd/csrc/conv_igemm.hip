@@ -1225,7 +1225,8 @@ bool conv_partial_n(ConvTile t, int Cout) {
 ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
     static int forced = -2;   // development knob: HMV_FORCE_TILE=<ConvTile> for layers with Cout > 64
     if (forced == -2) { const char *e = getenv("HMV_FORCE_TILE"); forced = e ? atoi(e) : -1; }
-    if (Cout > 64 && forced >= 0 && forced < TILE_COUNT) return (ConvTile)forced;
+    static const bool force_all = getenv("HMV_FORCE_TILE_ALL") != nullptr;   // ... and for the narrow layers too
+    if ((Cout > 64 || force_all) && forced >= 0 && forced < TILE_COUNT) return (ConvTile)forced;
     // Measured on MI355X (tools/conv_sweep.py): the matrix pipe is DVFS/power limited, so the tile with
     // the least L2->LDS traffic per FLOP wins as long as it still fills the 256 CUs for several rounds.
     // tiny-K expanding convs (layer1/2 conv3 + residual) are epilogue/HBM-bound: 4 small blocks per CU

@@ -1507,7 +1507,16 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     }
     switch (tile) {
         case TILE_128x32: return launch_modes<float, 128, 32, 4, 1, 32>(p, one, generic, s);
-        case TILE_128x64: return launch_modes<float, 128, 64, 2, 2, 32>(p, one, generic, s);
+        case TILE_128x64: {
+            // 64-channel 3x3 convs over many pixels (layer1 conv2): ONE 8-wave workgroup per 256 pixels instead of two 4-wave ones
+            // per 128 -- 664 -> 640 us (round 3; HMV_NO_T256x64=1 for A/B runs).  Same accumulation order: same bits.
+            static const bool no25664 = getenv("HMV_NO_T256x64") != nullptr;
+            if (!no25664 && !generic && !one && p.Cout == 64 && p.M >= 524288) {
+                if (name) *name = "conv_igemm_f32<256x64,taps>";
+                return launch_plain<float, 256, 64, 4, 2, 32>(p, false, s);
+            }
+            return launch_modes<float, 128, 64, 2, 2, 32>(p, one, generic, s);
+        }
         case TILE_128x128: return launch_modes<float, 128, 128, 2, 2, 32>(p, one, generic, s);
         case TILE_256x128: return launch_plain<float, 256, 128, 4, 2, 32>(p, one, s);
         case TILE_128x256: return launch_plain<float, 128, 256, 2, 4, 32>(p, one, s);

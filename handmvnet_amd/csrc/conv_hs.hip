@@ -314,6 +314,135 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_hs_stem_f32: the same structure for the fp32 path's stem (conv1 7x7 s2 as a 4x4 stride-1 convolution over 2x2 space-to-depth
+// frames of 12 channels, 48-byte pixels; conv_igemm: `128x64,dense`, six k-steps per tile, 0.53 of the fp32 MFMA peak).  A 16-byte chunk
+// is 4 channels and feeds four v_mfma_f32_32x32x2_f32 steps (k = 8 q + 4 kh + e: conv_igemm's pairing and order); the weights of a wave's
+// 32 channels are K / 2 = 96 registers; the accumulator starts at zero and the bias is added in the epilogue, (acc + bias) + 0 -> relu,
+// as conv_igemm's fp32 kernels do: bit-identical.  No residual.  4 waves along the pixels x 2 along the 64 channels.
+template <int NSLOT>
+__global__ __launch_bounds__(512, 2) void conv_hs_stem_f32(const ConvParams p) {
+    constexpr int R = 4, S = 4, CPP = 3, TM = 2, MW = 4, NW = 2, NT = 512;
+    constexpr int HH = 16 + R - 1, HW = 16 + S - 1, HROWS = HH * HW;
+    constexpr int NCH = R * S * CPP, NSTEP = NCH / 2;     // 48 chunks of 4 channels, 24 chunk pairs
+    constexpr int HP = (HROWS * CPP + NT - 1) / NT, SLOT = HP * NT * 16;
+    constexpr int D = NSLOT - 1, OS = TM * 4;
+    extern __shared__ __attribute__((aligned(16))) char hsm[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int mw = wave / NW, nw = wave - mw * NW;
+    const int n0 = nw * 32;
+    const int tyn = p.Ho >> 4, txn = p.Wo >> 4, per_img = tyn * txn, nblk = p.N * per_img;
+    const int ntl = nblk > (int)blockIdx.x ? (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    if (ntl == 0) return;
+
+    const float *zero32 = p.zero;
+    float *trash = const_cast<float *>(p.zero) + 64 + 4 * lane;
+    const float *Ain = reinterpret_cast<const float *>(p.in);
+    float *Out = reinterpret_cast<float *>(p.out);
+
+    // weights and bias -> registers, once: row n0 + l31, chunk pair Q: W[row][8 Q + 4 kh .. + 3]
+    hf32x4 wreg[NSTEP], bias[4];
+    {
+        const float *wb = reinterpret_cast<const float *>(p.wgt) + (size_t)(n0 + l31) * p.ldw + 4 * kh;
+#pragma unroll
+        for (int Q = 0; Q < NSTEP; ++Q) wreg[Q] = *reinterpret_cast<const hf32x4 *>(wb + 8 * Q);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const hf32x4 *>(p.bias + n0 + 8 * g + 4 * kh);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // halo DMA roles: unit L = 512 i + tid = chunk L % 3 of halo pixel L / 3; row << 24 | column << 16 | element offset inside an image row
+    int hyx[HP];
+#pragma unroll
+    for (int i = 0; i < HP; ++i) {
+        const int L = NT * i + tid, hp = L / CPP, ch = L - hp * CPP, hx = hp - (hp / HW) * HW;
+        hyx[i] = ((hp < HROWS ? hp / HW : 200) << 24) | (hx << 16) | (4 * (hx * CPP + ch));
+    }
+    auto block_origin = [&](int tt, int &n, int &by, int &bx) {
+        const int g = (int)blockIdx.x + tt * (int)gridDim.x;
+        n = g / per_img;
+        const int rem = g - n * per_img;
+        by = rem / txn;
+        bx = rem - by * txn;
+    };
+    auto issue_halo = [&](int tt) {
+        int n, by, bx;
+        block_origin(tt, n, by, bx);
+        const bool live = tt >= 0 && tt < ntl;
+        char *dst = hsm + (((tt % NSLOT) + NSLOT) % NSLOT) * SLOT + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < HP; ++i) {
+            int h = hyx[i];
+            asm volatile("" : "+v"(h));
+            const int iy = by * 16 - p.pad_h + (int)((unsigned)h >> 24), ix0 = bx * 16 - p.pad_w, ix = ix0 + ((h >> 16) & 255);
+            const bool ok = live && ((unsigned)h >> 24) < 200 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const float *src = ok ? Ain + ((unsigned)(((n * p.H + iy) * p.W + ix0) * (4 * CPP)) + ((unsigned)h & 0xffffu)) : zero32;
+            asm volatile("" : "+v"(src));   // ONE DMA instruction per schedule entry
+            HMV_HGLDS16(src, dst + i * (NT * 16));
+        }
+    };
+    for (int ft = -D; ft < 0; ++ft) {
+        issue_halo(ft + D);
+#pragma unroll
+        for (int i = 0; i < OS; ++i)
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(trash), "v"(hf32x4{0.f, 0.f, 0.f, 0.f}) : "memory");
+    }
+
+    const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    int hb[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) hb[a] = (2 * (mw * TM + a) + (l31 >> 4)) * HW + (l31 & 15);
+    hf32x16 acc[TM];
+    for (int tt = 0; tt < ntl; ++tt) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+        hs_wait_vm<hs_after_halo(D, HP, 0, OS)>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue_halo(tt + D);
+        const char *himg = hsm + (tt % NSLOT) * SLOT;
+        int hz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(hz));
+#pragma unroll
+        for (int Q = 0; Q < NSTEP; ++Q) {
+            const int gA = 2 * Q, gB = 2 * Q + 1;
+            const int tA = gA / CPP, cA = gA - tA * CPP, tB = gB / CPP, cB = gB - tB * CPP;
+            const int oA = (tA / S) * HW + tA % S, oB = (tB / S) * HW + tB % S;
+            hf32x4 px[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int u = (hb[a] + hz) * CPP + (kh ? oB * CPP + cB : oA * CPP + cA);
+                px[a] = *reinterpret_cast<const hf32x4 *>(himg + u * 16);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int a = 0; a < TM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[Q][e], px[a][e], acc[a], 0, 0, 0);
+            if ((Q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        int n, by, bx;
+        block_origin(tt, n, by, bx);
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const size_t pix = (size_t)(n * p.Ho + by * 16 + 2 * (mw * TM + a) + (l31 >> 4)) * p.Wo + bx * 16 + (l31 & 15);
+            float *orow = Out + pix * p.ldc + n0 + 4 * kh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                hf32x4 t;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = fmaxf((acc[a][4 * g + u] + bias[g][u]) + 0.f, lo);
+                float *dst = orow + 8 * g;
+                asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(t) : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
 // ====================================================================== host side
 static int g_hs_mode = -1;   // -1: the launcher's rule (HMV_NO_HS=1 disables it); 0 never; 1 whenever supported (op-level tests)
 void conv_hs_set_mode(int mode) { g_hs_mode = mode; }
@@ -329,11 +458,26 @@ static int hs_kind(const ConvParams &p) {
     if (p.R == 3 && p.S == 3 && p.pad_h == 1 && p.pad_w == 1 && p.Cin == 80 && p.Cout == 80 && p.Kpad == 768 && !p.rd_cout) return 4;
     return 0;
 }
+// fp32: the space-to-depth stem, 4x4 pad 2, 12 -> 64 channels (conv_hs_stem_f32)
+static bool hs_stem32(const ConvParams &p) {
+    return !p.in_f16 && !p.out_f16 && !p.res && p.R == 4 && p.S == 4 && p.pad_h == 2 && p.pad_w == 2 && p.Cin == 12 && p.Cout == 64 && p.Kpad == 192 && p.K == 192;
+}
 
 bool conv_hs_supported(const ConvParams &p) {
     static int off = -1;   // development knob: HMV_NO_HS=1 keeps these convs on conv_igemm (A/B runs)
     if (off < 0) off = getenv("HMV_NO_HS") ? 1 : 0;
     if (g_hs_mode == 0 || (g_hs_mode < 0 && off)) return false;
+    if (hs_stem32(p)) {
+        static const bool off32 = getenv("HMV_NO_HS32") != nullptr;   // development knob (A/B runs)
+        if (off32 && g_hs_mode <= 0) return false;
+        if (p.stride != 1 || p.up || p.in2 || p.ksl > 1 || p.phases > 1 || p.Ho != p.H || p.Wo != p.W || (p.H & 15) || (p.W & 15)) return false;
+        if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out || p.fill) return false;
+        if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
+        if ((p.lda ? p.lda : p.Cin) != 12 || ((p.ldw ? p.ldw : p.Kpad) & 3) || (p.ldc & 3) || p.ldc < 64) return false;
+        if ((long long)p.N * p.H * p.W * 12 >= (1ll << 31)) return false;
+        if (g_hs_mode > 0) return true;
+        return (long long)p.N * (p.H >> 4) * (p.W >> 4) >= 4 * 256;
+    }
     if (!hs_kind(p) || !p.in_f16 || !p.out_f16 || (p.res && !p.res_f16)) return false;
     if (p.stride != 1 || p.up || p.in2 || p.ksl > 1 || p.phases > 1 || p.Ho != p.H || p.Wo != p.W || p.H % hs_bh(hs_kind(p)) || (p.W & 15)) return false;
     if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out) return false;
@@ -366,6 +510,22 @@ static hipError_t launch_hs_one(const ConvParams &p, hipStream_t s) {
 }
 
 hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name) {
+    if (hs_stem32(p)) {
+        constexpr int NSLOT = 4, HP = (19 * 19 * 3 + 511) / 512;
+        constexpr size_t lds = (size_t)NSLOT * HP * 512 * 16;
+        static bool configured[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!configured[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_hs_stem_f32<NSLOT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            configured[dev] = true;
+        }
+        if (name) *name = "conv_hs_stem_f32<4x4,12->64>";
+        const int nblk = p.N * (p.H >> 4) * (p.W >> 4);
+        hipLaunchKernelGGL(conv_hs_stem_f32<NSLOT>, dim3(nblk < 256 ? nblk : 256), dim3(512), lds, s, p);
+        return hipGetLastError();
+    }
     switch (hs_kind(p)) {
         case 1:
             if (p.res) {

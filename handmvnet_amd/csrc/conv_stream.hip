@@ -497,7 +497,7 @@ static int stream32_shape(const ConvParams &p) {   // 0 none; 1 residual-bearing
     if (p.in_f16 || p.out_f16) return 0;            // 3 conv3 + downsample of layer1.0 (64 + 64 -> 256) as one GEMM over two sources
     if (p.in2) return (!p.res && p.Kpad == 128 && p.ksplit == 64 && p.Cout == 256 && p.lda == p.ksplit && p.lda2 % 4 == 0) ? 3 : 0;
     if (p.res) return (!p.res_f16 && (p.Kpad == 64 || p.Kpad == 128 || p.Kpad == 256) && p.Cout % 256 == 0 && 32 % (p.Cout / 256) == 0) ? 1 : 0;
-    return (p.Kpad == 256 && p.Cout == 64) ? 2 : 0;
+    return (p.Kpad == 256 && p.Cout == 64) ? 2 : ((p.Kpad == 64 && p.Cout == 64) ? 4 : 0);   // 4: layer1.0's conv1 64 -> 64
 }
 // ... all of which the launcher takes.  K = 64 and 128 (layer1 / layer2 conv3) are HBM-bound: 566 -> 489 us and 377 -> 359 us.  K = 256
 // (layer3 conv3) is MFMA-bound: as eight waves that reach their epilogue together it is 2.5 % SLOWER than conv_igemm's two paired
@@ -563,6 +563,7 @@ static hipError_t launch_stream32(ConvParams p, hipStream_t s) {
 hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **name) {
     if (const int k32 = stream32_shape(p)) {
         if (k32 == 2) { if (name) *name = "conv_stream_f32<128x64,k256>"; return launch_stream32<1, 1, 4, 2, 8, 8, false>(p, s); }
+        if (k32 == 4) { if (name) *name = "conv_stream_f32<128x64,k64>"; return launch_stream32<1, 1, 4, 2, 2, 8, false>(p, s); }
         if (k32 == 3) { if (name) *name = "conv_stream_f32<64x256,k128,dual>"; return launch_stream32<2, 1, 1, 8, 4, 8, false, true>(p, s); }
         if (p.Kpad == 256 && p.Cout % 128 == 0 && 64 % (p.Cout / 128) == 0) {   // four-wave workgroups, two per CU, 64 x 128 tiles
             if (name) *name = "conv_stream_f32<64x128,k256,res>";

@@ -378,7 +378,8 @@ def test_tall_tile_kernel(shape):
 STREAM32_SHAPES = [(4, 32, 32, 256, 1024, 1, 1, 0, True, True), (3, 17, 19, 128, 512, 1, 1, 0, True, True), (2, 32, 32, 64, 256, 1, 1, 0, True, False),
                    (1, 8, 8, 256, 256, 1, 1, 0, True, True), (20, 32, 32, 256, 1024, 1, 1, 0, True, True), (40, 32, 32, 128, 512, 1, 1, 0, True, True),
                    # the squeezing conv1 256 -> 64 without a residual (128 x 64 tiles)
-                   (2, 32, 32, 256, 64, 1, 1, 0, False, True), (3, 17, 19, 256, 64, 1, 1, 0, False, False), (48, 32, 32, 256, 64, 1, 1, 0, False, True)]
+                   (2, 32, 32, 256, 64, 1, 1, 0, False, True), (3, 17, 19, 256, 64, 1, 1, 0, False, False), (48, 32, 32, 256, 64, 1, 1, 0, False, True),
+                   (3, 32, 32, 64, 64, 1, 1, 0, False, True), (40, 32, 32, 64, 64, 1, 1, 0, False, False)]
 
 
 @pytest.mark.parametrize("shape", STREAM32_SHAPES)

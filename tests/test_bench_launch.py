@@ -95,6 +95,8 @@ def test_pmc_summary_names_the_round3_kernels_like_the_engine_does():
     assert ps.family("void hmv::conv_stream_f32<2, 1, 1, 8, 4, 8, false, true, false>(hmv::ConvParams)") == "conv_stream_f32<64x256,k128,dual>"
     assert ps.family("void hmv::conv_stream_f32<1, 1, 4, 2, 8, 8, false, false, false>(hmv::ConvParams)") == "conv_stream_f32<128x64,k256>"
     assert ps.family("void hmv::conv_stream_f32<2, 1, 1, 4, 8, 4, true, false, true>(hmv::ConvParams)") == "conv_stream_f32<64x128,k256,res>"
+    assert ps.family("void hmv::conv_hs_stem_f32<4>(hmv::ConvParams)") == "conv_hs_stem_f32<4x4,12->64>"
+    assert ps.family("void hmv::conv_igemm<float, 256, 64, 4, 2, 0, false, 32, false, false, false, false>(hmv::ConvParams)") == "conv_igemm_f32<256x64,taps>"
     assert ps.family("void hmv::conv_rds_f32<40, true, 4>(hmv::ConvParams)") == "conv_rds_f32<3x3,40->40,res>"
     assert ps.family("void hmv::conv_rds_f32<80, false, 8>(hmv::ConvParams)") == "conv_rds_f32<3x3,80->80>"
     assert ps.family("void hmv::conv_hs_f16<3, 3, 10, 2, 1, 2, 3, 3, true>(hmv::ConvParams)") == "conv_hs_f16<3x3,80->80,res>"

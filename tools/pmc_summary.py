@@ -61,6 +61,8 @@ def family(name: str) -> str:
     m = re.match(r"(?:void )?(?:hmv::)?conv_rds_f32<(\d+), (true|false), \d+>", name)
     if m:
         return f"conv_rds_f32<3x3,{m.group(1)}->{m.group(1)}" + (",res>" if m.group(2) == "true" else ">")
+    if re.match(r"(?:void )?(?:hmv::)?conv_hs_stem_f32<", name):
+        return "conv_hs_stem_f32<4x4,12->64>"
     if re.match(r"(?:void )?(?:hmv::)?conv_ht_f16\b", name) or name.startswith("_ZN3hmv11conv_ht_f16"):
         return "conv_ht_f16<512x128,3x3>"
     m = re.match(r"(?:void )?(?:hmv::)?conv_gemm8_f16<(true|false)>", name)

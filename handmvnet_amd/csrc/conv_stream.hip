@@ -96,13 +96,26 @@ static_assert(sched_after_piece(4, 3, 1, 8, 2, 8, 0) == 2 + 3 + 3 + 8 && sched_a
 // NT: 0 default cache policy, 1 residual rows non-temporal (read once), 2 pixel pieces too
 // DUAL: the reduction is the concatenation [first source | second source] (conv3 + downsample of a layer's first Bottleneck as one
 // GEMM, ConvParams::in2): pieces past ksplit come from the second tensor at pixel (ho * stride2, wo * stride2)
-template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool SPREAD = false, int NT_ = 0, bool DUAL = false>
+// N2 > 0 ("chain"): the launch also computes a FOLLOWING 1x1 conv with N2 output channels over its own output pixels (Bottleneck i's
+// conv3 -> Bottleneck i + 1's conv1, resnet.py:124-130).  The workgroup owns ALL BN = Cout channels of its pixel tile; after the
+// epilogue every wave writes its fp16 output block into an LDS image of the tile laid out like K2 = BN / 64 pixel pieces (for
+// residual-bearing launches: over the landing zone it has just consumed, which is exactly its [64-channel piece][rows] region), one
+// barrier, then wave (pixel block group, 32-channel block) runs the second GEMM's full reduction k ascending against weights it
+// holds in registers for the launch (BN / 4 VGPRs) and stores its [32 pixels][32 channels] blocks.  Operand roles, bias-as-initial-
+// accumulator, k16 order and epilogue arithmetic are those of the kernel that would have read the tensor back from HBM, so the
+// chained result is BIT-IDENTICAL to the two launches it replaces; its stores join the epilogue slot of the static schedule.
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool SPREAD = false, int NT_ = 0, bool DUAL = false, int N2 = 0>
 __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(const ConvParams p) {
     constexpr int NWV = MW * NW, NT = 64 * NWV;
     constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW;
     constexpr int D = NSLOT - 1;                 // pieces in flight ahead of the one being consumed
     constexpr int PA = BM * 8 / NT;              // pixel DMA instructions per piece and thread (a piece row = 8 x 16 bytes)
-    constexpr int RB = HAS_RES ? TM * TN * 2 : 0, OS = TM * TN * 2;
+    constexpr int NB2 = N2 / 32;                                   // chain: 32-channel output blocks of the second conv,
+    constexpr int TM2 = N2 ? (BM / 32) * NB2 / NWV : 0;            //   pixel blocks per wave (they share the wave's weight block),
+    constexpr int K2Q = BN / 16;                                   //   k16 steps of its reduction over this launch's BN channels
+    static_assert(N2 == 0 || (N2 % 32 == 0 && TN == 2 && TM2 >= 1 && NWV % NB2 == 0 && (BM / 32) == (NWV / NB2) * TM2),
+                  "chain: a wave's 64 output channels are one pixel piece of the second reduction; whole blocks per wave");
+    constexpr int RB = HAS_RES ? TM * TN * 2 : 0, OS = TM * TN * 2 + 2 * TM2;
     constexpr int RS = (SPREAD && HAS_RES) ? RB / NP : 0;
     static_assert(!SPREAD || RB % NP == 0, "spread schedule: whole residual DMAs per step");
     constexpr int ZW = TM * TN * 2 * 1024;       // bytes of one wave's residual landing zone
@@ -117,6 +130,9 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
     const int mw = wave / NW, nw = wave - mw * NW;
+    // landing zone of this wave; chain: zone (nw, mw) IS the region [piece nw][rows mw * TM * 32 ..] of the output tile's LDS image
+    const int zi = N2 ? nw * MW + mw : wave;
+    static_assert(N2 == 0 || !HAS_RES || ZW == TM * 32 * 128, "chain: a landing zone is the wave's region of the tile image");
 
     // ---- stream assignment: the nsl slices of one pixel stream are workgroups of ONE XCD (blockIdx & 7), dispatched together
     const int nsl = p.ntiles;                       // N-slices (Cout / BN), a divisor of 32
@@ -142,6 +158,14 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int Q = 0; Q < NP * 4; ++Q) wreg[b][Q] = *reinterpret_cast<const sf16x8 *>(wb + (size_t)(32 * b) * p.ldw + 16 * Q);
+    }
+    // chain: wave -> (pixel block group pg2, 32-channel block ob2) of the second conv; its weight block, the whole reduction
+    const int ob2 = N2 ? wave % (N2 ? NB2 : 1) : 0, pg2 = N2 ? wave / (N2 ? NB2 : 1) : 0;
+    sf16x8 w2reg[N2 ? K2Q : 1];
+    if constexpr (N2 > 0) {
+        const _Float16 *wb2 = reinterpret_cast<const _Float16 *>(p.nx_wgt) + (size_t)(32 * ob2 + wl31) * p.nx_ldw + 8 * kh;
+#pragma unroll
+        for (int Q = 0; Q < K2Q; ++Q) w2reg[Q] = *reinterpret_cast<const sf16x8 *>(wb2 + 16 * Q);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the counted waits below see only the schedule's own instructions
 
@@ -180,7 +204,7 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
         if constexpr (HAS_RES) {
             constexpr int first = decltype(first_c)::value, count = decltype(count_c)::value;
             const int mt = stream + tt * nstreams;
-            char *z = zones + ((tt & 1) * NWV + wave) * ZW;
+            char *z = zones + ((tt & 1) * NWV + zi) * ZW;
 #pragma unroll
             for (int idx = first; idx < first + count; ++idx) {
                 const int a = idx / (2 * TN), b = (idx / 2) % TN, j = idx & 1;
@@ -258,7 +282,115 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
         // ---- epilogue: acc (+ residual) -> relu -> fp16, 16-byte stores of 8 consecutive channels
         if constexpr (HAS_RES) wait_vm<sched_after_residual(NP, PA, RB, RS, OS)>();
         const int mt = stream + tt * nstreams;
-        const char *z = zones + ((tt & 1) * NWV + wave) * ZW + lane * 16;
+        const char *z = zones + ((tt & 1) * NWV + zi) * ZW + lane * 16;
+        if constexpr (N2 > 0) {
+            // the output tile's LDS image: [BN / 64 pieces][BM rows][64 channels], 16-byte chunks XOR-swizzled by the row like a pixel piece
+            char *yt = HAS_RES ? zones + (tt & 1) * NWV * ZW : zones;
+            sf16x8 rr[TM][TN][2], hv[TM][TN][2];
+            if constexpr (HAS_RES) {   // ALL residual vectors leave the zone before the first output vector is written over it
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) rr[a][b][j] = *reinterpret_cast<const sf16x8 *>(z + ((a * TN + b) * 2 + j) * 1024);
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int m = mt * BM + (mw * TM + a) * 32 + l31;
+                _Float16 *orow = Out + (size_t)m * p.ldc + n0 + 8 * kh;
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        sf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if constexpr (HAS_RES) r = rr[a][b][j];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) hv[a][b][j][u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + (float)r[u], lo);
+                        _Float16 *dst = m < p.M ? orow + 32 * b + 16 * j : trash;
+                        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(hv[a][b][j]) : "memory");
+                        if constexpr (!HAS_RES) {   // no landing zone under the image: the vector can go to LDS at once
+                            const unsigned ya = (unsigned)(size_t)(__attribute__((address_space(3))) char *)yt +
+                                                (unsigned)((nw * BM + (mw * TM + a) * 32 + l31) * 128 + (((4 * b + 2 * j + kh) ^ fsw) * 16));
+                            asm volatile("ds_write_b128 %0, %1" ::"v"(ya), "v"(hv[a][b][j]) : "memory");
+                        }
+                    }
+            }
+            // Inline asm: a C++ store to LDS makes the compiler wait for every LDS-DMA in flight (it cannot tell the zones apart).
+            // Residual-bearing: the writes go over the zone the residual vectors were read from -- every hv depends on its rr, so all
+            // reads have RETURNED before the first write is issued
+            if constexpr (HAS_RES) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const unsigned ya = (unsigned)(size_t)(__attribute__((address_space(3))) char *)yt +
+                                            (unsigned)((nw * BM + (mw * TM + a) * 32 + l31) * 128 + (((4 * b + 2 * j + kh) ^ fsw) * 16));
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(ya), "v"(hv[a][b][j]) : "memory");
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the tile image is complete
+            // ---- second conv: bias as the initial accumulator, k ascending in 16-element blocks (conv_stream<..,kBN> / conv_igemm's order)
+            const __attribute__((address_space(4))) float *bq =
+                (const __attribute__((address_space(4))) float *)(p.nx_bias + __builtin_amdgcn_readfirstlane(32 * ob2)) + bz;
+            sf32x16 acc2[TM2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = 16 * (e >> 3) + (e & 7);
+                const float v0 = bq[c], v1 = bq[c + 8];
+                const float v = kh ? v1 : v0;
+#pragma unroll
+                for (int a = 0; a < TM2; ++a) acc2[a][e] = v;
+            }
+            const unsigned yr = (unsigned)(size_t)(__attribute__((address_space(3))) char *)yt + (unsigned)((pg2 * TM2 * 32 + l31) * 128);
+            // fragment reads in groups of four, group g + 1 requested before group g's MFMAs; the counted lgkmcnt names the
+            // registers it releases (the compiler does not see the asm reads' latency: the "+v" operands order the MFMAs behind the wait)
+            constexpr int G = 4 / TM2, NG = K2Q / G;
+            static_assert(K2Q % G == 0 && G * TM2 == 4, "four fragment reads per group");
+            sf16x8 px[2][G][TM2];
+#define HMV_CHAIN_READ_GROUP(g)                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) _Pragma("unroll") for (int a = 0; a < TM2; ++a) {                                \
+        const int Q = (g) * G + i;                                                                                                  \
+        const unsigned ad = yr + (unsigned)(((Q >> 2) * BM + a * 32) * 128) + (unsigned)((((2 * (Q & 3) + kh) ^ fsw)) * 16);        \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(px[(g) & 1][i][a]) : "v"(ad) : "memory");                                         \
+    }
+            HMV_CHAIN_READ_GROUP(0)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                sf16x8(&pg)[G][TM2] = px[g & 1];
+                if (g + 1 < NG) {
+                    HMV_CHAIN_READ_GROUP(g + 1)
+                    if constexpr (TM2 == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(pg[0][0]), "+v"(pg[1][0]), "+v"(pg[2][0]), "+v"(pg[3][0]) :: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(pg[0][0]), "+v"(pg[0][1]), "+v"(pg[1][0]), "+v"(pg[1][1]) :: "memory");
+                } else {
+                    if constexpr (TM2 == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pg[0][0]), "+v"(pg[1][0]), "+v"(pg[2][0]), "+v"(pg[3][0]) :: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pg[0][0]), "+v"(pg[0][1]), "+v"(pg[1][0]), "+v"(pg[1][1]) :: "memory");
+                }
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int a = 0; a < TM2; ++a) acc2[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2reg[g * G + i], pg[i][a], acc2[a], 0, 0, 0);
+            }
+#undef HMV_CHAIN_READ_GROUP
+            const float lo2 = (p.nx_act == ACT_RELU) ? 0.f : -INFINITY;
+            _Float16 *Out2 = reinterpret_cast<_Float16 *>(p.nx_out);
+#pragma unroll
+            for (int a = 0; a < TM2; ++a) {
+                const int m = mt * BM + (pg2 * TM2 + a) * 32 + l31;
+                _Float16 *orow = Out2 + (size_t)m * p.nx_ldc + 32 * ob2 + 8 * kh;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const sf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+                    sf16x8 h2;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) h2[u] = (_Float16)fmaxf(acc2[a][8 * j + u] * p.acc_scale + (float)r[u], lo2);
+                    _Float16 *dst = m < p.M ? orow + 16 * j : trash;
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(h2) : "memory");
+                }
+            }
+        } else {
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int m = mt * BM + (mw * TM + a) * 32 + l31;
@@ -278,6 +410,7 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
                     _Float16 *dst = m < p.M ? orow + 32 * b + 16 * j : trash;
                     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(hv) : "memory");
                 }
+        }
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
@@ -447,13 +580,15 @@ __global__ __launch_bounds__(64 * MW *NW, 2) void conv_stream_f32(const ConvPara
 }
 
 // ====================================================================== host side
-template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool SPREAD = false, int NT_ = 0, bool DUAL = false>
+template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool SPREAD = false, int NT_ = 0, bool DUAL = false, int N2 = 0>
 static hipError_t launch_stream_one(ConvParams p, hipStream_t s) {
     constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW, NWV = MW * NW;
-    constexpr size_t lds = (size_t)NSLOT * BM * 128 + (HAS_RES ? (size_t)2 * NWV * TM * TN * 2 * 1024 : 0);
+    // chain without landing zones: the output tile's LDS image has its own BM x BN x 2 bytes behind the ring
+    constexpr size_t lds = (size_t)NSLOT * BM * 128 + (HAS_RES ? (size_t)2 * NWV * TM * TN * 2 * 1024 : (N2 ? (size_t)BM * BN * 2 : 0));
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool configured[64] = {};
-    auto kern = conv_stream_f16<TM, TN, MW, NW, NP, NSLOT, HAS_RES, SPREAD, NT_, DUAL>;
+    auto kern = conv_stream_f16<TM, TN, MW, NW, NP, NSLOT, HAS_RES, SPREAD, NT_, DUAL, N2>;
+    if (N2 && (p.Cout != BN || p.nx_cout != N2 || !p.nx_wgt || !p.nx_bias || !p.nx_out)) return hipErrorInvalidValue;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
@@ -540,6 +675,20 @@ bool conv_stream_supported(const ConvParams &p) {
     return (long long)(p.M + bm - 1) / bm >= (long long)min_tiles * streams;
 }
 
+// chain (ConvParams::nx_*): the fp16 launches whose workgroup owns all output channels of its pixel tile -- Bottleneck conv3 of layer1
+// (64 -> 256 + residual; conv3 + downsample of layer1.0 as two sources) -- followed by a 1x1 conv 256 -> 64 / 128 + ReLU
+bool conv_stream_chain_ok(const ConvParams &q, int nx_cout) {
+    static const bool off = getenv("HMV_NO_CHAIN") != nullptr;   // development knob (A/B runs)
+    if (off || (nx_cout != 64 && nx_cout != 128)) return false;
+    ConvParams p = q;
+    p.nx_wgt = nullptr;
+    if (!p.lda) p.lda = p.Cin;
+    if (!p.ldw) p.ldw = p.Kpad;
+    if (!p.in_f16 || !p.out_f16 || p.acc_shift || p.Cout != 256 || (p.ldc & 7)) return false;
+    if (!(p.in2 ? (!p.res && p.Kpad == 128 && p.ksplit == 64 && nx_cout == 64) : (p.res && p.Kpad == 64))) return false;
+    return conv_stream_supported(p);
+}
+
 template <int TM, int TN, int MW, int NW, int NP, int NSLOT, bool HAS_RES, bool DUAL = false, bool HALF = false>
 static hipError_t launch_stream32(ConvParams p, hipStream_t s) {
     constexpr int BM = 32 * TM * MW, BN = 32 * TN * NW;
@@ -589,6 +738,22 @@ hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **n
         case 100: if (p.Kpad == 256) return launch_stream_one<__VA_ARGS__, true, true, 0>(p, s);            \
                   return launch_stream_one<__VA_ARGS__, true, false, 0>(p, s);                              \
         default: return launch_stream_one<__VA_ARGS__, true, false, 0>(p, s);                               \
+    }
+    if (p.nx_wgt) {   // chained launches (conv_stream_chain_ok): pixel ring of four pieces + the output tile's image
+        if (p.nx_ldw < p.Cout || (p.nx_ldw & 7) || (p.nx_ldc & 7) || (p.nx_act != ACT_NONE && p.nx_act != ACT_RELU) || p.acc_shift) return hipErrorInvalidValue;
+        if (p.in2 && p.Kpad == 128 && p.nx_cout == 64) {
+            if (name) *name = "conv_stream_f16<128x256,k128,dual,+1x1:64>";
+            return launch_stream_one<2, 2, 2, 4, 2, 4, false, false, 0, true, 64>(p, s);
+        }
+        if (p.res && p.Kpad == 64 && p.nx_cout == 64) {
+            if (name) *name = "conv_stream_f16<128x256,k64,res,+1x1:64>";
+            return launch_stream_one<2, 2, 2, 4, 1, 2, true, false, 0, false, 64>(p, s);
+        }
+        if (p.res && p.Kpad == 64 && p.nx_cout == 128) {
+            if (name) *name = "conv_stream_f16<128x256,k64,res,+1x1:128>";
+            return launch_stream_one<2, 2, 2, 4, 1, 2, true, false, 0, false, 128>(p, s);
+        }
+        return hipErrorInvalidValue;
     }
     if (p.in2) {
         if (p.Kpad == 128) {

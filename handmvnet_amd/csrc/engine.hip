@@ -208,6 +208,7 @@ struct hmv_engine {
     // fused tail kernels (fusion_kernels.hip); HMV_NO_FFFUSE=1 / HMV_NO_CHEBFUSE=1 in the environment or hmv_set_tail_fusion(h, 0)
     // select the launch-per-op path (A/B runs, the equivalence test).  Part of the workspace plan: changing them re-plans.
     bool ff_fuse = true, cheb_fuse = true;
+    bool chain_fuse = true;   // conv3 -> next block's conv1 in one launch (conv_stream.hip chain); hmv_set_chain_fusion(h, 0) / HMV_NO_CHAIN=1
     std::vector<GraphEntry> gcache;
     std::vector<GraphKey> gseen;     // buffer sets run eagerly once and not captured yet (callers often alternate between a few)
     hipStream_t gstream = nullptr;   // capture happens here (the caller's stream may be the NULL stream, which cannot capture)
@@ -1076,6 +1077,11 @@ struct Runner {
     // second A source of the next conv() call (conv3 + downsample as one GEMM); consumed by that call
     struct Dual { const float *in2 = nullptr; int ksplit = 0, H2 = 0, W2 = 0, lda2 = 0, stride2 = 1; } dual;
     const char **kernel_name = nullptr;   // op-level entries: receives the kernel family of the last launch
+    // chained 1x1 conv of the next conv() call (conv_stream.hip: Bottleneck i's conv3 -> Bottleneck i + 1's conv1 from the output tile
+    // while it is in LDS); consumed by that call.  `probe`: the next conv() call only fills *probe with the launch it WOULD make (also
+    // in the planning run) -- what chain_ok() asks conv_stream_chain_ok about
+    struct Chain { const Layer *L = nullptr; float *out = nullptr; } chain;
+    ConvParams *probe = nullptr;
 
     // Bottleneck conv3 + BN3 + downsample conv + BN + ReLU in one launch: out = relu([t2 | x(strided)] . Wcat + b)
     void conv_dual(const Layer &L, const float *t2, int planes, const float *x, int inpl, int N, int Hx, int Wx, int stride, float *out,
@@ -1088,7 +1094,7 @@ struct Runner {
     void conv(const Layer &L, const float *in, int N, int H, int W, int stride, int pad_h, int pad_w, float *out, int ldc,
               const float *res, int ldr, int act, int Ho, int Wo, int rg_out = 0, int rg_in = 0, int scatter = 0, int ooy = 0,
               int oox = 0, bool out_f16 = false, int up = 0, bool fill = false) {
-        if (dry || rc != HMV_OK) return;
+        if ((dry && !probe) || rc != HMV_OK) { probe = nullptr; return; }
         ConvParams p{};
         p.in = in; p.wgt = L.w; p.bias = L.bias; p.res = res; p.out = out;
         if (ksplit > 1) { p.ksl = ksplit; p.kslice = L.Kpad / ksplit; p.out_slice = (size_t)N * Ho * Wo * ldc; }
@@ -1117,6 +1123,13 @@ struct Runner {
             if (out_f16) { p.out_split = 1; p.ldc = 2 * ldc; }
             if (res) { p.res_split = 1; p.ldr = 2 * ldr; }
         }
+        if (probe) { *probe = p; probe = nullptr; return; }
+        const Layer *Lx = chain.L;
+        if (Lx) {
+            p.nx_wgt = Lx->w; p.nx_bias = Lx->bias; p.nx_out = chain.out; p.nx_cout = Lx->Cout; p.nx_ldw = Lx->Kpad; p.nx_ldc = Lx->Cout;
+            p.nx_act = ACT_RELU;
+            chain = Chain();
+        }
         // split layers walk 3x the reduction on fp16 MFMAs: the tile rules see the real reduction length
         const ConvTile tile = conv_pick_tile(p.M, p.Cout, L.plane ? p.K / (L.x3n ? 2 : 3) : p.K, L.f16, res != nullptr);
         ProfRec *pr = nullptr;
@@ -1128,7 +1141,7 @@ struct Runner {
                 h->prof.push_back(r);
             }
             pr = &h->prof[h->prof_used++];
-            pr->label = L.label;
+            pr->label = Lx ? L.label + "+" + Lx->label : L.label;
             // algorithmic FLOPs: the real (un-padded) reduction length; the stem's 4th channel is padding
             const double kreal = L.Kreal ? (double)L.Kreal : (double)L.K;   // real channels only (no padding FLOPs)
             const double cout_real = L.rd_cout ? (double)L.rd_cout : (double)L.Cout;
@@ -1149,6 +1162,10 @@ struct Runner {
             if (dual.in2)   // [t2 | x]: t2 at every output pixel, x at the pixels the stride keeps
                 pr->bytes = ((double)p.M * dual.ksplit + (double)p.M * (kreal - dual.ksplit)) * eb_in + (double)L.Cout * kreal * eb_in +
                             (double)p.M * cout_real * eb_out;
+            if (Lx) {   // the chained conv: its weights and output rows; its input rows never leave the CU
+                pr->flops += 2.0 * (double)p.M * (double)Lx->Cout * (double)Lx->K;
+                pr->bytes += (double)Lx->Cout * (double)Lx->K * eb_in + (double)p.M * (double)Lx->Cout * eb_out;
+            }
             check(hipEventRecord(pr->e0, s), "hipEventRecord");
         }
         const char *kname = nullptr;
@@ -1445,6 +1462,7 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     // ---- residual layers (resnet.py:223-239; Bottleneck 124-144; BasicBlock 90-106)
     float *level[3] = {nullptr, nullptr, nullptr};
     int lc[3], lh[3], lw[3];
+    float *t1_chained = nullptr;
     for (int li = 0; li < 3; ++li) {
         for (size_t bi = 0; bi < h->blocks[li].size(); ++bi) {
             const Block &b = h->blocks[li][bi];
@@ -1454,16 +1472,36 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
             if (h->paper) {
                 const int planes = b.c1.Cout;
                 outc = b.c3.Cout;
-                float *t1 = R.alloc(ACT((size_t)N * hh * ww * planes));
-                R.conv(b.c1, cur, N, hh, ww, 1, 0, 0, t1, planes, nullptr, 0, ACT_RELU, hh, ww, 0, 0, 0, 0, 0, h16);
+                float *t1 = t1_chained;   // conv1 + BN + ReLU of this block came out of the previous block's chained conv3 launch
+                t1_chained = nullptr;
+                if (!t1) {
+                    t1 = R.alloc(ACT((size_t)N * hh * ww * planes));
+                    R.conv(b.c1, cur, N, hh, ww, 1, 0, 0, t1, planes, nullptr, 0, ACT_RELU, hh, ww, 0, 0, 0, 0, 0, h16);
+                }
                 float *t2 = R.alloc(ACT((size_t)N * ho * wo * planes));
                 R.conv(b.c2, t1, N, hh, ww, b.stride, 1, 1, t2, planes, nullptr, 0, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, h16);
                 R.release(t1);
+                // the block behind this one (of this layer or the first of the next): its conv1 reads this block's output and nothing
+                // else, so a conv3 launch whose workgroup holds all channels of its pixels computes it from the tile in LDS
+                // (conv_stream.hip "chain"; fp16 layer1 at large batches: the 256-channel tensor is read once less per block).
+                // Bit-identical to the two launches, so the choice may depend on the launch size (conv_stream_chain_ok)
+                const Block *nb = bi + 1 < h->blocks[li].size() ? &h->blocks[li][bi + 1] : (li + 1 < 3 && !h->blocks[li + 1].empty() ? &h->blocks[li + 1][0] : nullptr);
+                const bool nb_ok = h->chain_fuse && nb && h16 && !split && nb->c1.f16 && !nb->c1.plane && nb->c1.R == 1 && nb->c1.S == 1 &&
+                                   nb->c1.Cin == outc && nb->c1.K == outc && nb->c1.Kpad == outc && !nb->c1.tall && !nb->c1.rd_cout;
                 const float *res = cur;
                 float *dsb = nullptr;
                 if (b.fused_ds) {   // conv3 and the downsample branch as one GEMM over [t2 | x]
                     y = R.alloc(ACT((size_t)N * ho * wo * outc));
+                    bool ch = false;
+                    if (nb_ok) {
+                        ConvParams q{};
+                        R.probe = &q;
+                        R.conv_dual(b.c3ds, t2, planes, cur, C, N, hh, ww, b.stride, y, outc, ho, wo, h16);
+                        ch = conv_stream_chain_ok(q, nb->c1.Cout);
+                    }
+                    if (ch) { t1_chained = R.alloc(ACT((size_t)N * ho * wo * nb->c1.Cout)); R.chain.L = &nb->c1; R.chain.out = t1_chained; }
                     R.conv_dual(b.c3ds, t2, planes, cur, C, N, hh, ww, b.stride, y, outc, ho, wo, h16);
+                    R.chain = Runner::Chain();
                 } else {
                     if (b.has_ds) {
                         dsb = R.alloc(ACT((size_t)N * ho * wo * outc));
@@ -1471,7 +1509,16 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                         res = dsb;
                     }
                     y = R.alloc(ACT((size_t)N * ho * wo * outc));
+                    bool ch = false;
+                    if (nb_ok) {
+                        ConvParams q{};
+                        R.probe = &q;
+                        R.conv(b.c3, t2, N, ho, wo, 1, 0, 0, y, outc, res, outc, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, h16);
+                        ch = conv_stream_chain_ok(q, nb->c1.Cout);
+                    }
+                    if (ch) { t1_chained = R.alloc(ACT((size_t)N * ho * wo * nb->c1.Cout)); R.chain.L = &nb->c1; R.chain.out = t1_chained; }
                     R.conv(b.c3, t2, N, ho, wo, 1, 0, 0, y, outc, res, outc, ACT_RELU, ho, wo, 0, 0, 0, 0, 0, h16);
+                    R.chain = Runner::Chain();
                 }
                 R.release(t2);
                 R.release(dsb);
@@ -1944,6 +1991,18 @@ int hmv_set_tail_fusion(hmv_handle h, int32_t enable) {
     h->drop_graphs();
     h->ff_fuse = h->cheb_fuse = enable != 0;
     h->reserved_batch = 0;   // forces hmv_reserve to size the workspace again
+    return HMV_OK;
+}
+
+/* Chained launches (Bottleneck conv3 -> the next block's conv1 from the output tile in LDS) on (default) / off (one launch per conv:
+ * the same bits).  Part of the workspace plan, so the workspace is re-planned on the next forward. */
+int hmv_set_chain_fusion(hmv_handle h, int32_t enable) {
+    if (!h) return HMV_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    h->drop_graphs();
+    h->chain_fuse = enable != 0;
+    h->reserved_batch = 0;
     return HMV_OK;
 }
 

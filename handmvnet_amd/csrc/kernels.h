@@ -68,6 +68,14 @@ struct ConvParams {
     int stagger_blocks; //   phase groups that begin 0 / 1 / 2 / 3 x `stagger` 10-ns ticks late, so that the load / compute / drain
                         //   phases of the 256 CUs do not march in lockstep (speed only: any placement gives the same result)
     unsigned long long *dbg;  // diagnostic builds only: per-block {shader cycles, 100 MHz ticks} of the main loop
+    // conv_stream.hip chain: a FOLLOWING 1x1 conv + BN + ReLU over this launch's output pixels (Bottleneck i's conv3 -> Bottleneck
+    // i + 1's conv1, resnet.py:124-130) computed from the output tile while it is still in LDS -- the wide tensor is written once and
+    // not read again by that conv.  nx_out[m][nx_ldc] = act(sum_k out[m][k] * nx_wgt[n][k] + nx_bias[n]), k < Cout; fp16 rows.
+    // Only launches for which conv_stream_chain_ok(p, nx_cout) holds may set these.
+    const void *nx_wgt;
+    const float *nx_bias;
+    void *nx_out;
+    int nx_cout, nx_ldw, nx_ldc, nx_act;
 };
 
 enum ConvTile { TILE_128x32 = 0, TILE_128x64 = 1, TILE_128x128 = 2, TILE_256x128 = 3, TILE_128x256 = 4, TILE_256x256 = 5,
@@ -87,6 +95,9 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
 // conv_stream.hip: persistent weight-stationary 1x1 convolution (fp16 rows, residual-bearing, short reductions, many pixels);
 // launch_conv routes to it when conv_stream_supported(p).  Bit-identical to conv_igemm's result.
 bool conv_stream_supported(const ConvParams &p);
+// true when launch_conv(p) would run on a conv_stream instantiation that can also compute a following 1x1 conv with nx_cout output
+// channels (p as for the launch itself, nx_* fields unset or set)
+bool conv_stream_chain_ok(const ConvParams &p, int nx_cout);
 void conv_stream_set_mode(int mode);   // -1 launcher's rule, 0 never, 1 whenever the shape has an instantiation (op-level tests)
 hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **name);
 

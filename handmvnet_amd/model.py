@@ -347,6 +347,11 @@ class HandMvNet(torch.nn.Module):
         for h in self._engines.values():
             _lib.check(_lib.load().hmv_set_tail_fusion(h, int(enable)), h)
 
+    def set_chain_fusion(self, enable: bool = True):
+        """Chained conv3 -> next conv1 launches on (default) / off (one launch per conv, same bits) for the engines built so far."""
+        for h in self._engines.values():
+            _lib.check(_lib.load().hmv_set_chain_fusion(h, int(enable)), h)
+
     def poison_workspace(self, value: int = 0xFF):
         """Test hook: fills the workspace of the engine the last forward ran on with `value` bytes (0xFF = NaN patterns)."""
         hh, ww, idx, _, dt = self._last_key

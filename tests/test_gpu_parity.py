@@ -549,6 +549,37 @@ def test_full_size_properties(mode):
     assert cam <= (fp16_bounds("cfg3s_r50_v8_256")["joints_cam"] if mode == "f16" else TOL_CAM), (mode, cam)
 
 
+def test_chained_launches_give_the_bits_of_one_launch_per_conv():
+    """conv_stream.hip "chain": on the fp16 path at large batches a layer1 Bottleneck's conv3 launch also computes the NEXT block's
+    conv1 from its output tile in LDS (resnet.py:124-144 / 128-130; three launches fewer, the 256-channel tensor read once less per
+    block).  Same operand roles, k order and epilogue arithmetic as the launch it absorbs: every output and the layer3 feature map
+    must equal the unchained forward's BIT FOR BIT (32 frames of 256 x 256 = the smallest batch the chain takes), a ragged batch
+    (33 frames: a partial last pixel tile) too, and the poisoned-workspace rule must still hold."""
+    from handmvnet_amd import HandMvNet
+    from handmvnet_amd.synth import synth_inputs
+    cfg, (tp, mp, dp), sd, _, _ = load_case("cfg3s_r50_v8_256")
+    m = HandMvNet(tp, mp, dp)
+    m.load_state_dict(sd)
+    m.half()
+    dev = torch.device("cuda:0")
+    for nb in (4, 5):
+        x, bbox, intr = synth_inputs(cfg, nb, 7 + nb, 256)
+        m.set_chain_fusion(True)
+        chained = _run(m, x, bbox, intr)
+        n_chained = m.launch_count()
+        m.poison_workspace(0xFF)
+        again = _run(m, x, bbox, intr)
+        m.set_chain_fusion(False)
+        plain = _run(m, x, bbox, intr)
+        n_plain = m.launch_count()
+        assert n_plain - n_chained == 3, (nb, n_plain, n_chained)
+        for k in ("feat0", "heatmap", "tokens", "joints_cam", "joints_crop_img"):
+            assert np.isfinite(chained[k]).all(), k
+            assert np.array_equal(chained[k], plain[k]), (nb, k, float(np.abs(chained[k] - plain[k]).max()))
+            assert np.array_equal(chained[k], again[k]), (nb, k)
+    m.set_chain_fusion(True)
+
+
 _CFG2_REF = {}
 
 

@@ -62,7 +62,13 @@ constexpr int hs_after_residual(int HP, int RB, int OS) { return OS + HP + RB; }
 // rows of the BH x 16 output block) and TN 32-channel blocks per wave; BH = 2 MW TM is 16 (eight waves) or, where the weights of
 // a 32-channel block take most of a wave's registers (80 -> 80 channels: 180 of them), 8 rows under THREE waves (one per
 // 32-channel block, one wave per SIMD: each may then use the 512 registers of its SIMD lane).
-template <int R, int S, int CPP, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES>
+// POOL (the stem): the launch also applies the MaxPool2d(3, stride 2, padding 1) that follows conv1 + BN + ReLU (resnet.py:218-221).  Blocks
+// of 16 x 16 conv outputs are laid 14 apart (origin 14 b - 1), so each holds every conv output that the 7 x 7 pooled pixels 7 b .. 7 b + 6
+// need: the epilogue puts the block's fp16 outputs into an LDS tile instead of HBM, one barrier, then 392 threads (pooled pixel, 8
+// channels) take the maximum over the window positions that lie inside the conv map -- maxpool3s2_f16_kernel's arithmetic on the same
+// fp16 values, so the pooled map is BIT-IDENTICAL to conv + pool as two launches -- and store ONE 16-byte vector each.  The conv map
+// (8x the pooled map's bytes) is never written or read; 1.3x the conv FLOPs are recomputed on a kernel that is nowhere near MFMA-bound.
+template <int R, int S, int CPP, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES, bool POOL = false>
 __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f16(const ConvParams p) {
     constexpr int NWV = MW * NW, NT = 64 * NWV;
     constexpr int BH = 2 * MW * TM;                    // output rows of a block
@@ -71,7 +77,8 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
     constexpr int HP = (HROWS * CPP + NT - 1) / NT;    // DMA instructions per halo image and thread
     constexpr int SLOT = HP * NT * 16;                 // bytes of one halo image (padded to whole passes)
     constexpr int D = NSLOT - 1;
-    constexpr int RB = HAS_RES ? TM * TN * 2 : 0, OS = TM * TN * 2;
+    constexpr int RB = HAS_RES ? TM * TN * 2 : 0, OS = POOL ? 1 : TM * TN * 2;
+    static_assert(!POOL || (!HAS_RES && BH == 16 && NT == 512 && TN * NW == 2), "pooled epilogue: 16 x 16 blocks of 64 channels, eight waves");
     constexpr int ZW = TM * TN * 2 * 1024;
     constexpr int NSTEP = (NCH + 1) / 2;
     constexpr bool SWZ = CPP == 8;                     // 128-byte pixels: XOR swizzle; 80- / 32-byte pixels are conflict-free as they lie
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
     const int n0 = nw * TN * 32;                       // this wave's first output channel
 
     // ---- the blocks of this workgroup: b = blockIdx.x, + gridDim.x, ...
-    const int tyn = p.Ho / BH, txn = p.Wo >> 4, per_img = tyn * txn, nblk = p.N * per_img;
+    const int tyn = POOL ? (p.pool_h + 6) / 7 : p.Ho / BH, txn = POOL ? (p.pool_w + 6) / 7 : p.Wo >> 4, per_img = tyn * txn, nblk = p.N * per_img;
     const int ntl = nblk > (int)blockIdx.x ? (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     if (ntl == 0) return;
 
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
         for (int i = 0; i < HP; ++i) {
             int h = hyx[i];
             asm volatile("" : "+v"(h));   // its fields are this block's arithmetic: hoisted, each would hold a register for the launch
-            const int iy = by * BH - p.pad_h + (int)((unsigned)h >> 24), ix0 = bx * 16 - p.pad_w, ix = ix0 + ((h >> 16) & 255);
+            const int iy = (POOL ? by * 14 - 1 : by * BH) - p.pad_h + (int)((unsigned)h >> 24), ix0 = (POOL ? bx * 14 - 1 : bx * 16) - p.pad_w, ix = ix0 + ((h >> 16) & 255);
             const bool ok = live && ((unsigned)h >> 24) < 200 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             // (32-bit element index: conv_hs_supported keeps N H W lda below 2^31.  A 64-bit form lets the compiler keep one
             // block-invariant base POINTER per pass: ten registers the 80-channel variant does not have)
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
         // requested BEFORE the MFMAs of step Q, into the other of two register sets, and waited for with a COUNTED lgkmcnt: the
         // reads are inline asm (the compiler, left to track them, reuses one register set and drains the LDS queue before every MFMA
         // group -- 3x the MFMA time), the wait names the registers it releases so that no MFMA can move above it.
-        constexpr bool PIPE = !SWZ && CPP % 2 == 0 && CPP > 2;   // (the stem's 32-byte pixels keep the plain loop)
+        constexpr bool PIPE = !SWZ && CPP % 2 == 0;
         hf16x8 pxs[2][TM];
         if constexpr (PIPE) {
             // an even CPP keeps the two chunks of a k16 step inside one tap: lanes 32-63 read 16 bytes behind lanes 0-31, and the
@@ -288,6 +295,54 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
         int n, by, bx;
         block_origin(tt, n, by, bx);
         const char *z = zones + ((tt & 1) * NWV + wave) * ZW + lane * 16;
+        if constexpr (POOL) {
+            // the block's outputs -> LDS tile [256 pixels][64 channels], 16-byte chunks XOR-swizzled by the pixel (inline asm: a C++ store
+            // to LDS makes the compiler wait for every LDS-DMA in flight)
+            const unsigned tile = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)zones;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int pxl = 32 * (mw * TM + a) + l31;
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        hf16x8 hv;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + 0.f, lo);
+                        const unsigned ad = tile + (unsigned)(pxl * 128 + ((((n0 >> 3) + 4 * b + 2 * j + kh) ^ (pxl & 7)) * 16));
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(hv) : "memory");
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // pooled pixel (py, px) of the block x 8 channels per thread; window rows 2 py .. 2 py + 2 of the tile = conv rows 14 by - 1 + ..
+            const int pp = tid >> 3, c8 = tid & 7, py = pp / 7, pxx = pp - 7 * py;
+            const int gy = 7 * by + py, gx = 7 * bx + pxx;
+            hf16x8 m;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m[u] = (_Float16)(-65504.f);
+            {   // all nine window vectors are requested at once (every window lies inside the tile; threads past the 49 pooled pixels
+                // read pixel 0 and store to the trash page); positions outside the conv map count as the smallest fp16, as in the pool kernel
+                const int py_ = pp < 49 ? py : 0, px_ = pp < 49 ? pxx : 0;
+                hf16x8 wv[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int pl = (2 * py_ + r) * 16 + 2 * px_ + q;
+                        wv[r][q] = *reinterpret_cast<const hf16x8 *>(zones + pl * 128 + ((c8 ^ (pl & 7)) * 16));
+                    }
+                const hf16x8 lowest = m;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const bool in = (unsigned)(14 * by - 1 + 2 * py_ + r) < (unsigned)p.Ho && (unsigned)(14 * bx - 1 + 2 * px_ + q) < (unsigned)p.Wo;
+                        m = __builtin_elementwise_max(m, in ? wv[r][q] : lowest);
+                    }
+            }
+            _Float16 *dst = (pp < 49 && gy < p.pool_h && gx < p.pool_w) ? Out + ((size_t)(n * p.pool_h + gy) * p.pool_w + gx) * p.ldc + 8 * c8 : trash;
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(m) : "memory");
+        } else {
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const size_t pix = (size_t)(n * p.Ho + by * BH + 2 * (mw * TM + a) + (l31 >> 4)) * p.Wo + bx * 16 + (l31 & 15);
@@ -309,6 +364,7 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
             // (the 80-channel variant holds 180 weight registers: finish one pixel block before the next one's residual vectors,
             // accumulator copies and results become live)
             if constexpr (CPP == 10) __builtin_amdgcn_sched_barrier(0);
+        }
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -467,6 +523,12 @@ bool conv_hs_supported(const ConvParams &p) {
     static int off = -1;   // development knob: HMV_NO_HS=1 keeps these convs on conv_igemm (A/B runs)
     if (off < 0) off = getenv("HMV_NO_HS") ? 1 : 0;
     if (g_hs_mode == 0 || (g_hs_mode < 0 && off)) return false;
+    if (p.pool) {   // conv + ReLU + MaxPool2d(3, 2, 1) in one launch: the fp16 stem only, at least four 7 x 7 pooled blocks per workgroup
+        static const bool nopool = getenv("HMV_NO_STEMPOOL") != nullptr;   // development knob (A/B runs)
+        if (nopool || hs_kind(p) != 2 || !p.in_f16 || !p.out_f16 || p.res || p.fill || p.act != ACT_RELU) return false;
+        if (p.pool_h != (p.Ho + 2 - 3) / 2 + 1 || p.pool_w != (p.Wo + 2 - 3) / 2 + 1 || p.ldc != 64) return false;
+        if (g_hs_mode <= 0 && (long long)p.N * ((p.pool_h + 6) / 7) * ((p.pool_w + 6) / 7) < 4 * 256) return false;
+    }
     if (hs_stem32(p)) {
         static const bool off32 = getenv("HMV_NO_HS32") != nullptr;   // development knob (A/B runs)
         if (off32 && g_hs_mode <= 0) return false;
@@ -489,14 +551,14 @@ bool conv_hs_supported(const ConvParams &p) {
     return (long long)p.N * (p.H / hs_bh(hs_kind(p))) * (p.W >> 4) >= 4 * 256;   // at least four blocks per workgroup
 }
 
-template <int R, int S, int CPP, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES>
+template <int R, int S, int CPP, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES, bool POOL = false>
 static hipError_t launch_hs_one(const ConvParams &p, hipStream_t s) {
     constexpr int NWV = MW * NW, NT = 64 * NWV, BH = 2 * MW * TM;
     constexpr int HROWS = (BH + R - 1) * (16 + S - 1), HP = (HROWS * CPP + NT - 1) / NT;
-    constexpr size_t lds = (size_t)NSLOT * HP * NT * 16 + (HAS_RES ? (size_t)2 * NWV * TM * TN * 2 * 1024 : 0);
+    constexpr size_t lds = (size_t)NSLOT * HP * NT * 16 + (HAS_RES ? (size_t)2 * NWV * TM * TN * 2 * 1024 : 0) + (POOL ? 256 * 128 : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool configured[64] = {};
-    auto kern = conv_hs_f16<R, S, CPP, TM, TN, MW, NW, NSLOT, HAS_RES>;
+    auto kern = conv_hs_f16<R, S, CPP, TM, TN, MW, NW, NSLOT, HAS_RES, POOL>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
@@ -504,7 +566,7 @@ static hipError_t launch_hs_one(const ConvParams &p, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured[dev] = true;
     }
-    const int nblk = p.N * (p.H / BH) * (p.W >> 4);
+    const int nblk = POOL ? p.N * ((p.pool_h + 6) / 7) * ((p.pool_w + 6) / 7) : p.N * (p.H / BH) * (p.W >> 4);
     hipLaunchKernelGGL(kern, dim3(nblk < 256 ? nblk : 256), dim3(NT), lds, s, p);
     return hipGetLastError();
 }
@@ -535,8 +597,22 @@ hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name)
             if (name) *name = "conv_hs_f16<3x3,64->64>";
             return launch_hs_one<3, 3, 8, 2, 1, 4, 2, 3, false>(p, s);   // no landing zones: three halo images (two in flight)
         case 2:
+            // eight waves along the pixels, both 32-channel blocks per wave (128 weight registers): every pixel fragment read from LDS
+            // feeds TWO MFMAs.  With one block per wave (4 x 2 waves) a k16 step is one 1 KB LDS read per 32-cycle MFMA on every SIMD --
+            // exactly the LDS peak of the CU (128 B / clk), and the kernel ran at 0.34 MFMA-busy
+            {
+                static const bool old_split = getenv("HMV_STEM_4x2") != nullptr;   // development knob (A/B runs): the round-3 wave split
+                if (old_split && !p.pool) {
+                    if (name) *name = "conv_hs_f16<4x4,16->64>";
+                    return launch_hs_one<4, 4, 2, 2, 1, 4, 2, 4, false>(p, s);
+                }
+            }
+            if (p.pool) {
+                if (name) *name = "conv_hs_f16<4x4,16->64,+maxpool>";
+                return launch_hs_one<4, 4, 2, 1, 2, 8, 1, 4, false, true>(p, s);
+            }
             if (name) *name = "conv_hs_f16<4x4,16->64>";
-            return launch_hs_one<4, 4, 2, 2, 1, 4, 2, 4, false>(p, s);
+            return launch_hs_one<4, 4, 2, 1, 2, 8, 1, 4, false>(p, s);
         case 3:   // 40-channel pixels: 26 KB halo images
             if (p.res) {
                 if (name) *name = "conv_hs_f16<3x3,40->40,res>";

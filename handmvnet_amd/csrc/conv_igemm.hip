@@ -1352,6 +1352,8 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     const bool one = p.R == 1 && p.S == 1 && p.pad_h == 0 && p.pad_w == 0;
     // a chained 1x1 conv (ConvParams::nx_*) exists in conv_stream.hip only: the caller asked conv_stream_chain_ok first
     if (p.nx_wgt && (generic || p.tall || !conv_stream_chain_ok(p, p.nx_cout))) return hipErrorInvalidValue;
+    // ... and a fused max pool in conv_hs.hip only
+    if (p.pool && (generic || p.tall || !conv_hs_supported(p))) return hipErrorInvalidValue;
     // weights packed for the tall-tile 3x3 kernel (conv_ht.hip; K order (32-channel chunk, r, s, c % 32)): that kernel when its 512-pixel x
     // 128-channel tiles fill the chip, else the 64 x 64 / 128 x 128 tiles of this file walking the SAME order -- same operand roles,
     // same accumulation sequence, same epilogue arithmetic, so the bits do not depend on which of the two ran (tests/test_gpu_parity.py)

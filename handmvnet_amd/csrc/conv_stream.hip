@@ -603,7 +603,7 @@ static hipError_t launch_stream_one(ConvParams p, hipStream_t s) {
 }
 
 // shapes with an instantiation.  Residual-bearing (Bottleneck conv3): (K, BN) = (256, 512), (128, 512), (64, 256).  Without a residual
-// (the squeezing conv1 of layer1 / layer2, resnet.py:128-130): (K, Cout) = (256, 64), (512, 128), (256, 128), all of Cout in one slice.
+// (the squeezing conv1 of layer1 / layer2, resnet.py:128-130): (K, Cout) = (256, 64), (512, 128), (256, 128), (64, 64), all of Cout in one slice.
 // Returns the channel-slice width BN (0: none) and the pixel-tile height through *bm.
 static int stream_bn(const ConvParams &p, int *bm = nullptr) {
     int bn = 0, m = 0;
@@ -617,6 +617,7 @@ static int stream_bn(const ConvParams &p, int *bm = nullptr) {
         if (p.Kpad == 256 && p.Cout == 64) { bn = 64; m = 256; }
         else if (p.Kpad == 512 && p.Cout == 128) { bn = 128; m = 128; }
         else if (p.Kpad == 256 && p.Cout == 128) { bn = 128; m = 128; }
+        else if (p.Kpad == 64 && p.Cout == 64) { bn = 64; m = 256; }   // layer1.0's conv1 (resnet.py:128-130 on the pooled stem output)
     }
     if (bm) *bm = m;
     return bn;
@@ -767,6 +768,10 @@ hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **n
         if (p.Kpad == 256 && p.Cout == 64) {
             if (name) *name = "conv_stream_f16<256x64,k256>";
             return launch_stream_one<1, 2, 8, 1, 4, 4, false>(p, s);
+        }
+        if (p.Kpad == 64 && p.Cout == 64) {
+            if (name) *name = "conv_stream_f16<256x64,k64>";
+            return launch_stream_one<1, 2, 8, 1, 1, 4, false>(p, s);
         }
         if (p.Kpad == 512) {
             if (name) *name = "conv_stream_f16<128x128,k512>";

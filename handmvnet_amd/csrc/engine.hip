@@ -1082,6 +1082,8 @@ struct Runner {
     // in the planning run) -- what chain_ok() asks conv_stream_chain_ok about
     struct Chain { const Layer *L = nullptr; float *out = nullptr; } chain;
     ConvParams *probe = nullptr;
+    // MaxPool2d(3, 2, 1) fused into the next conv() call (conv_hs.hip, the fp16 stem): `out` is then the pooled map; consumed by that call
+    struct Pool { int h = 0, w = 0; } pool;
 
     // Bottleneck conv3 + BN3 + downsample conv + BN + ReLU in one launch: out = relu([t2 | x(strided)] . Wcat + b)
     void conv_dual(const Layer &L, const float *t2, int planes, const float *x, int inpl, int N, int Hx, int Wx, int stride, float *out,
@@ -1123,6 +1125,8 @@ struct Runner {
             if (out_f16) { p.out_split = 1; p.ldc = 2 * ldc; }
             if (res) { p.res_split = 1; p.ldr = 2 * ldr; }
         }
+        const bool pooled = pool.h > 0;
+        if (pooled) { p.pool = 1; p.pool_h = pool.h; p.pool_w = pool.w; pool = Pool(); }
         if (probe) { *probe = p; probe = nullptr; return; }
         const Layer *Lx = chain.L;
         if (Lx) {
@@ -1141,7 +1145,7 @@ struct Runner {
                 h->prof.push_back(r);
             }
             pr = &h->prof[h->prof_used++];
-            pr->label = Lx ? L.label + "+" + Lx->label : L.label;
+            pr->label = Lx ? L.label + "+" + Lx->label : (pooled ? L.label + "+maxpool" : L.label);
             // algorithmic FLOPs: the real (un-padded) reduction length; the stem's 4th channel is padding
             const double kreal = L.Kreal ? (double)L.Kreal : (double)L.K;   // real channels only (no padding FLOPs)
             const double cout_real = L.rd_cout ? (double)L.rd_cout : (double)L.Cout;
@@ -1162,6 +1166,8 @@ struct Runner {
             if (dual.in2)   // [t2 | x]: t2 at every output pixel, x at the pixels the stride keeps
                 pr->bytes = ((double)p.M * dual.ksplit + (double)p.M * (kreal - dual.ksplit)) * eb_in + (double)L.Cout * kreal * eb_in +
                             (double)p.M * cout_real * eb_out;
+            if (pooled)   // the conv map never reaches HBM: input, weights, the pooled map
+                pr->bytes = in_px * cin_real * eb_in + (double)L.Cout * kreal * eb_in + (double)N * p.pool_h * p.pool_w * cout_real * eb_out;
             if (Lx) {   // the chained conv: its weights and output rows; its input rows never leave the CU
                 pr->flops += 2.0 * (double)p.M * (double)Lx->Cout * (double)Lx->K;
                 pr->bytes += (double)Lx->Cout * (double)Lx->K * eb_in + (double)p.M * (double)Lx->Cout * eb_out;
@@ -1311,9 +1317,15 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         float *cur = R.alloc(ACT((size_t)N * H2 * W2 * 64));
         R.conv(hr.conv2, c1, N, H1, W1, 2, 1, 1, cur, 64, nullptr, 0, ACT_RELU, H2, W2, 0, 0, 0, 0, 0, h16);
         R.release(c1);
-        for (const Block &b : hr.layer1) {   // 4 Bottlenecks, planes 64 -> 256 channels
-            float *t1 = R.alloc(ACT((size_t)N * H2 * W2 * 64));
-            R.conv(b.c1, cur, N, H2, W2, 1, 0, 0, t1, 64, nullptr, 0, ACT_RELU, H2, W2, 0, 0, 0, 0, 0, h16);
+        float *t1_chained = nullptr;
+        for (size_t bi = 0; bi < hr.layer1.size(); ++bi) {   // 4 Bottlenecks, planes 64 -> 256 channels
+            const Block &b = hr.layer1[bi];
+            float *t1 = t1_chained;   // (conv_stream.hip chain, as in the ResNet loop below: the previous block's conv3 launch computed it)
+            t1_chained = nullptr;
+            if (!t1) {
+                t1 = R.alloc(ACT((size_t)N * H2 * W2 * 64));
+                R.conv(b.c1, cur, N, H2, W2, 1, 0, 0, t1, 64, nullptr, 0, ACT_RELU, H2, W2, 0, 0, 0, 0, 0, h16);
+            }
             float *t2 = R.alloc(ACT((size_t)N * H2 * W2 * 64));
             R.conv(b.c2, t1, N, H2, W2, 1, 1, 1, t2, 64, nullptr, 0, ACT_RELU, H2, W2, 0, 0, 0, 0, 0, h16);
             R.release(t1);
@@ -1325,7 +1337,18 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                 res = dsb;
             }
             float *y = R.alloc(ACT((size_t)N * H2 * W2 * 256));
+            const Block *nb = bi + 1 < hr.layer1.size() ? &hr.layer1[bi + 1] : nullptr;
+            bool ch = false;
+            if (h->chain_fuse && nb && h16 && !split && nb->c1.f16 && !nb->c1.plane && nb->c1.R == 1 && nb->c1.S == 1 && nb->c1.Cin == 256 &&
+                nb->c1.K == 256 && nb->c1.Kpad == 256 && !nb->c1.tall && !nb->c1.rd_cout) {
+                ConvParams q{};
+                R.probe = &q;
+                R.conv(b.c3, t2, N, H2, W2, 1, 0, 0, y, 256, res, 256, ACT_RELU, H2, W2, 0, 0, 0, 0, 0, h16);
+                ch = conv_stream_chain_ok(q, nb->c1.Cout);
+            }
+            if (ch) { t1_chained = R.alloc(ACT((size_t)N * H2 * W2 * 64)); R.chain.L = &nb->c1; R.chain.out = t1_chained; }
             R.conv(b.c3, t2, N, H2, W2, 1, 0, 0, y, 256, res, 256, ACT_RELU, H2, W2, 0, 0, 0, 0, 0, h16);
+            R.chain = Runner::Chain();
             R.release(t2);
             R.release(dsb);
             R.release(cur);
@@ -1449,15 +1472,35 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     if (h->fsrc.frames) LAUNCH(launch_frames_to_input(h->fsrc.frames, h->fsrc.boxes, N, h->fsrc.fh, h->fsrc.fw, H, W, h->fsrc.mean, h->fsrc.std, smode, in4, s, /*s2d=*/true));
     else LAUNCH(launch_nchw_to_s2d(x, in4, N, H, W, smode, s));
     const int H1 = (H + 6 - 7) / 2 + 1, W1 = (W + 6 - 7) / 2 + 1;   // == Hs, Ws
-    float *c1 = R.alloc(ACT((size_t)N * H1 * W1 * 64));
-    R.conv(h->stem, in4, N, Hs, Ws, 1, 2, 2, c1, 64, nullptr, 0, ACT_RELU, H1, W1, 0, 0, 0, 0, 0, h16);
-    R.release(in4);
     int hh = (H1 + 2 - 3) / 2 + 1, ww = (W1 + 2 - 3) / 2 + 1, C = 64;
-    float *cur = R.alloc(ACT((size_t)N * hh * ww * 64));
-    if (split) LAUNCH(launch_maxpool3s2_split(c1, cur, N, H1, W1, 64, hh, ww, s));
-    else if (h16) LAUNCH(launch_maxpool3s2_f16(c1, cur, N, H1, W1, 64, hh, ww, s));
-    else LAUNCH(launch_maxpool3s2(c1, cur, N, H1, W1, 64, hh, ww, s));
-    R.release(c1);
+    // fp16, many frames: conv1 + BN + ReLU + maxpool as ONE launch (conv_hs.hip's pooled epilogue: the 64-channel conv map, 8x the
+    // pooled map's bytes, never reaches HBM).  Bit-identical to the two launches, so the choice may depend on the launch size
+    bool stem_pool = false;
+    if (h16 && !split && h->chain_fuse) {
+        ConvParams q{};
+        R.probe = &q;
+        R.pool.h = hh; R.pool.w = ww;
+        R.conv(h->stem, in4, N, Hs, Ws, 1, 2, 2, nullptr, 64, nullptr, 0, ACT_RELU, H1, W1, 0, 0, 0, 0, 0, h16);
+        R.pool = Runner::Pool();
+        stem_pool = q.pool && conv_hs_supported(q);
+    }
+    float *cur;
+    if (stem_pool) {
+        cur = R.alloc(ACT((size_t)N * hh * ww * 64));
+        R.pool.h = hh; R.pool.w = ww;
+        R.conv(h->stem, in4, N, Hs, Ws, 1, 2, 2, cur, 64, nullptr, 0, ACT_RELU, H1, W1, 0, 0, 0, 0, 0, h16);
+        R.pool = Runner::Pool();
+        R.release(in4);
+    } else {
+        float *c1 = R.alloc(ACT((size_t)N * H1 * W1 * 64));
+        R.conv(h->stem, in4, N, Hs, Ws, 1, 2, 2, c1, 64, nullptr, 0, ACT_RELU, H1, W1, 0, 0, 0, 0, 0, h16);
+        R.release(in4);
+        cur = R.alloc(ACT((size_t)N * hh * ww * 64));
+        if (split) LAUNCH(launch_maxpool3s2_split(c1, cur, N, H1, W1, 64, hh, ww, s));
+        else if (h16) LAUNCH(launch_maxpool3s2_f16(c1, cur, N, H1, W1, 64, hh, ww, s));
+        else LAUNCH(launch_maxpool3s2(c1, cur, N, H1, W1, 64, hh, ww, s));
+        R.release(c1);
+    }
 
     // ---- residual layers (resnet.py:223-239; Bottleneck 124-144; BasicBlock 90-106)
     float *level[3] = {nullptr, nullptr, nullptr};

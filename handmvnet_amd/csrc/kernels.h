@@ -72,6 +72,9 @@ struct ConvParams {
     // i + 1's conv1, resnet.py:124-130) computed from the output tile while it is still in LDS -- the wide tensor is written once and
     // not read again by that conv.  nx_out[m][nx_ldc] = act(sum_k out[m][k] * nx_wgt[n][k] + nx_bias[n]), k < Cout; fp16 rows.
     // Only launches for which conv_stream_chain_ok(p, nx_cout) holds may set these.
+    // conv_hs.hip: the launch also applies MaxPool2d(3, stride 2, padding 1) to its (ReLU) output (the stem, resnet.py:218-221): `out` is the
+    // pooled map [N][pool_h][pool_w][ldc]; Ho x Wo stay the conv map's dims.  Only launches conv_hs_supported(p) accepts may set it.
+    int pool, pool_h, pool_w;
     const void *nx_wgt;
     const float *nx_bias;
     void *nx_out;

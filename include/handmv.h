@@ -105,10 +105,11 @@ int hmv_reserve(hmv_handle h, int32_t batch);
  * and the equivalence test; the workspace is re-planned on the next forward. */
 int hmv_set_tail_fusion(hmv_handle h, int32_t enable);
 
-/* Chained launches (conv_stream.hip: a Bottleneck's conv3 + residual and the NEXT Bottleneck's conv1 + BN + ReLU,
- * /root/reference/src/models/backbones/resnet.py:124-144, as ONE launch that computes the second conv from the first one's output tile
- * while it is still on the CU; fp16 path, layer1, large batches) on (default) or off (one launch per conv; also HMV_NO_CHAIN=1 in
- * the environment).  Both give the same bits; A/B runs and the identity test; the workspace is re-planned on the next forward. */
+/* Cross-layer launches of the fp16 backbone at large batches: conv_stream.hip's chain (a Bottleneck's conv3 + residual and the NEXT
+ * Bottleneck's conv1 + BN + ReLU, /root/reference/src/models/backbones/resnet.py:124-144, as ONE launch that computes the second conv
+ * from the first one's output tile while it is still on the CU; layer1) and conv_hs.hip's pooled stem (conv1 + BN + ReLU + MaxPool2d,
+ * resnet.py:218-221, as one launch), on (default) or off (one launch per op; also HMV_NO_CHAIN=1 / HMV_NO_STEMPOOL=1 in the environment).
+ * Both give the same bits; A/B runs and the identity test; the workspace is re-planned on the next forward. */
 int hmv_set_chain_fusion(hmv_handle h, int32_t enable);
 
 /* Test hook: fills the reserved workspace with the byte `value` (0xFF: NaNs) on `stream`.  No stage may read workspace bytes that

@@ -260,7 +260,9 @@ STREAM_SHAPES = [(4, 32, 32, 256, 1024, 1, 1, 0, True, True), (3, 17, 19, 256, 5
                  (40, 64, 64, 64, 256, 1, 1, 0, True, True),
                  # without a residual: the squeezing conv1 shapes (K, Cout) = (256, 64), (512, 128), (256, 128)
                  (4, 64, 64, 256, 64, 1, 1, 0, False, True), (3, 17, 19, 256, 64, 1, 1, 0, False, False), (40, 64, 64, 256, 64, 1, 1, 0, False, True),
-                 (8, 32, 32, 512, 128, 1, 1, 0, False, True), (1, 33, 31, 512, 128, 1, 1, 0, False, True), (12, 64, 64, 256, 128, 1, 1, 0, False, True)]
+                 (8, 32, 32, 512, 128, 1, 1, 0, False, True), (1, 33, 31, 512, 128, 1, 1, 0, False, True), (12, 64, 64, 256, 128, 1, 1, 0, False, True),
+                 # layer1.0's conv1 (64 -> 64)
+                 (4, 64, 64, 64, 64, 1, 1, 0, False, True), (3, 17, 19, 64, 64, 1, 1, 0, False, False), (40, 64, 64, 64, 64, 1, 1, 0, False, True)]
 
 
 # 1x1 convs without a residual on the phase-interleaved 256 x 256 tile (conv_gemm8.hip): K from 2 to 16 k-steps, ragged pixel and
@@ -549,20 +551,23 @@ def test_full_size_properties(mode):
     assert cam <= (fp16_bounds("cfg3s_r50_v8_256")["joints_cam"] if mode == "f16" else TOL_CAM), (mode, cam)
 
 
-def test_chained_launches_give_the_bits_of_one_launch_per_conv():
-    """conv_stream.hip "chain": on the fp16 path at large batches a layer1 Bottleneck's conv3 launch also computes the NEXT block's
-    conv1 from its output tile in LDS (resnet.py:124-144 / 128-130; three launches fewer, the 256-channel tensor read once less per
-    block).  Same operand roles, k order and epilogue arithmetic as the launch it absorbs: every output and the layer3 feature map
-    must equal the unchained forward's BIT FOR BIT (32 frames of 256 x 256 = the smallest batch the chain takes), a ragged batch
-    (33 frames: a partial last pixel tile) too, and the poisoned-workspace rule must still hold."""
+@pytest.mark.parametrize("case,frames_per_sample,fewer", [("cfg3s_r50_v8_256", 8, 4), ("hr40_v4_128", 4, 3)])
+def test_chained_launches_give_the_bits_of_one_launch_per_conv(case, frames_per_sample, fewer):
+    """Cross-layer launches of the fp16 backbone at large batches.  conv_stream.hip "chain": a layer1 Bottleneck's conv3 launch also
+    computes the NEXT block's conv1 from its output tile in LDS (resnet.py:124-144 / 128-130; three launches fewer, the 256-channel
+    tensor read once less per block).  conv_hs.hip "+maxpool": the stem conv's epilogue applies the 3x3 / 2 max pool to its block in
+    LDS (resnet.py:218-221; the 64-channel conv map never reaches HBM).  Same operand roles, k order and epilogue arithmetic as the
+    launches they absorb: every output and the layer3 feature map must equal the one-launch-per-op forward's BIT FOR BIT (32 frames
+    of 256 x 256 = the smallest batch the chain takes), a ragged batch (40 / 36 frames) too, and the poisoned-workspace rule must still
+    hold.  HRNet-w40's layer1 (four Bottlenecks, hrnet.py:96-140) takes the chain too (no pooled stem there: three launches fewer)."""
     from handmvnet_amd import HandMvNet
     from handmvnet_amd.synth import synth_inputs
-    cfg, (tp, mp, dp), sd, _, _ = load_case("cfg3s_r50_v8_256")
+    cfg, (tp, mp, dp), sd, _, _ = load_case(case)
     m = HandMvNet(tp, mp, dp)
     m.load_state_dict(sd)
     m.half()
     dev = torch.device("cuda:0")
-    for nb in (4, 5):
+    for nb in (32 // frames_per_sample, 32 // frames_per_sample + 1):
         x, bbox, intr = synth_inputs(cfg, nb, 7 + nb, 256)
         m.set_chain_fusion(True)
         chained = _run(m, x, bbox, intr)
@@ -572,7 +577,7 @@ def test_chained_launches_give_the_bits_of_one_launch_per_conv():
         m.set_chain_fusion(False)
         plain = _run(m, x, bbox, intr)
         n_plain = m.launch_count()
-        assert n_plain - n_chained == 3, (nb, n_plain, n_chained)
+        assert n_plain - n_chained == fewer, (nb, n_plain, n_chained)
         for k in ("feat0", "heatmap", "tokens", "joints_cam", "joints_crop_img"):
             assert np.isfinite(chained[k]).all(), k
             assert np.array_equal(chained[k], plain[k]), (nb, k, float(np.abs(chained[k] - plain[k]).max()))

@@ -197,7 +197,13 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
     for (int a = 0; a < TM; ++a) hb[a] = (2 * (mw * TM + a) + (l31 >> 4)) * HW + (l31 & 15);
     hf32x16 acc[TM][TN];
 
+    // diagnostic launches only (hmv_bench_conv with HMV_BENCH_CLOCK=1): shader cycles workgroup 0's first wave spends per phase, summed
+    // over its blocks -- {halo wait + barrier, main loop, epilogue, blocks, total}
+    unsigned long long ph_wait = 0, ph_main = 0, ph_epi = 0, ph_t0 = 0;
+    if (p.dbg) ph_t0 = __builtin_amdgcn_s_memtime();
     for (int tt = 0; tt < ntl; ++tt) {
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+        if (p.dbg) ts0 = __builtin_amdgcn_s_memtime();
         int bz;   // bias re-read per block behind an opaque zero offset (scalar cache): hoisted it would cost 16 TN VGPRs
         asm volatile("s_mov_b32 %0, 0" : "=s"(bz));
         const __attribute__((address_space(4))) float *bp = bp0 + bz;
@@ -213,6 +219,7 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
             }
         hs_wait_vm<hs_after_halo(D, HP, RB, OS)>();                           // my share of halo(tt) has landed
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // everyone's has; everyone is done with halo(tt - 1)
+        if (p.dbg) ts1 = __builtin_amdgcn_s_memtime();
         issue_halo(tt + D);                                                   // ... whose slot takes halo(tt + D)
         issue_R(tt + 1);
         const char *himg = hsm + (tt % NSLOT) * SLOT;
@@ -291,6 +298,7 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
             }
         }
         // ---- epilogue
+        if (p.dbg) { asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][15])); ts2 = __builtin_amdgcn_s_memtime(); }
         if constexpr (HAS_RES) hs_wait_vm<hs_after_residual(HP, RB, OS)>();
         int n, by, bx;
         block_origin(tt, n, by, bx);
@@ -366,8 +374,12 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
             if constexpr (CPP == 10) __builtin_amdgcn_sched_barrier(0);
         }
         }
+        if (p.dbg) { const unsigned long long ts3 = __builtin_amdgcn_s_memtime(); ph_wait += ts1 - ts0; ph_main += ts2 - ts1; ph_epi += ts3 - ts2; }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (p.dbg && blockIdx.x == 0 && tid == 0) {
+        p.dbg[0] = ph_wait; p.dbg[1] = ph_main; p.dbg[2] = ph_epi; p.dbg[3] = (unsigned long long)ntl; p.dbg[4] = __builtin_amdgcn_s_memtime() - ph_t0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

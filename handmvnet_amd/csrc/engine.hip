@@ -1026,6 +1026,8 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
             if (const char *dump = getenv("HMV_BENCH_DUMP")) {
                 if (FILE *f = fopen(dump, "wb")) { fwrite(hd.data(), 8, hd.size(), f); fclose(f); }
             }
+            if (getenv("HMV_BENCH_PHASES"))   // conv_hs.hip: {wait, main loop, epilogue} cycles of workgroup 0's first wave, blocks, total
+                fprintf(stderr, "[phases] wait %llu main %llu epilogue %llu blocks %llu total %llu\n", hd[0], hd[1], hd[2], hd[3], hd[4]);
             std::vector<double> clk, cyc;
             for (int i = 0; i < nblk_dbg; ++i)
                 if (hd[8 * i + 1] > 0) { clk.push_back((double)hd[8 * i] / (double)hd[8 * i + 1] * 0.1); cyc.push_back((double)hd[8 * i]); }

@@ -91,6 +91,14 @@ def test_pmc_summary_names_the_round3_kernels_like_the_engine_does():
     assert ps.family("void hmv::conv_hs_f16<3, 3, 5, 2, 1, 4, 2, 3, true>(hmv::ConvParams)") == "conv_hs_f16<3x3,40->40,res>"
     assert ps.family("void hmv::conv_hs_f16<4, 4, 2, 2, 1, 4, 2, 4, false>(hmv::ConvParams)") == "conv_hs_f16<4x4,16->64>"
     assert ps.family("hmv::conv_ht_f16(hmv::ConvParams)") == "conv_ht_f16<512x128,3x3>"
+    # the chained / pooled launches (template arguments N2 and POOL)
+    assert ps.family("void hmv::conv_stream_f16<2, 2, 2, 4, 2, 8, false, false, 0, true, 0>(hmv::ConvParams)") == "conv_stream_f16<128x256,k128,dual>"
+    assert ps.family("void hmv::conv_stream_f16<2, 2, 2, 4, 2, 4, false, false, 0, true, 64>(hmv::ConvParams)") == "conv_stream_f16<128x256,k128,dual,+1x1:64>"
+    assert ps.family("void hmv::conv_stream_f16<2, 2, 2, 4, 1, 2, true, false, 0, false, 128>(hmv::ConvParams)") == "conv_stream_f16<128x256,k64,res,+1x1:128>"
+    assert ps.family("void hmv::conv_stream_f16<1, 2, 8, 1, 1, 4, false, false, 0, false, 0>(hmv::ConvParams)") == "conv_stream_f16<256x64,k64>"
+    assert ps.family("void hmv::conv_hs_f16<4, 4, 2, 1, 2, 8, 1, 4, false, true>(hmv::ConvParams)") == "conv_hs_f16<4x4,16->64,+maxpool>"
+    assert ps.family("void hmv::conv_hs_f16<4, 4, 2, 1, 2, 8, 1, 4, false, false>(hmv::ConvParams)") == "conv_hs_f16<4x4,16->64>"
+    assert ps.family("void hmv::conv_hs_f16<3, 3, 8, 2, 1, 4, 2, 2, true, false>(hmv::ConvParams)") == "conv_hs_f16<3x3,64->64,res>"
     assert ps.family("void hmv::conv_stream_f32<2, 1, 1, 8, 2, 4, true, false, false>(hmv::ConvParams)") == "conv_stream_f32<64x256,k64,res>"
     assert ps.family("void hmv::conv_stream_f32<2, 1, 1, 8, 4, 8, false, true, false>(hmv::ConvParams)") == "conv_stream_f32<64x256,k128,dual>"
     assert ps.family("void hmv::conv_stream_f32<1, 1, 4, 2, 8, 8, false, false, false>(hmv::ConvParams)") == "conv_stream_f32<128x64,k256>"

@@ -39,25 +39,27 @@ def family(name: str) -> str:
         k16 = ",k16" if (m.group(4) == "32" and not c32) else ""
         return f"conv_igemm_f16<{m.group(1)}x{m.group(2)}{k16}," + {"0": "taps", "1": "1x1", "2": "dense", "3": "halo"}[m.group(3)] + \
             (",rowsum" if m.group(5) == "1" else "") + (",c32" if c32 else "") + ">"
-    # round 3: conv_stream_f16<TM, TN, MW, NW, NP, NSLOT, HAS_RES, SPREAD, NT> and conv_gemm8_f16<DUAL>
+    # round 3: conv_stream_f16<TM, TN, MW, NW, NP, NSLOT, HAS_RES, SPREAD, NT, DUAL, N2> and conv_gemm8_f16<DUAL>
     m = re.match(r"(?:void )?(?:hmv::)?conv_stream_f16<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, (true|false)", name)
     if m:
         tm, tn, mw, nw, np_ = (int(m.group(i)) for i in range(1, 6))
         targs = name[name.index("<") + 1:name.index(">")].split(", ")
-        tail = ",res>" if m.group(6) == "true" else (",dual>" if len(targs) >= 10 and targs[9] == "true" else ">")
-        return f"conv_stream_f16<{32 * tm * mw}x{32 * tn * nw},k{64 * np_}" + tail
+        tail = ",res" if m.group(6) == "true" else (",dual" if len(targs) >= 10 and targs[9] == "true" else "")
+        if len(targs) >= 11 and targs[10] != "0":   # N2: the chained 1x1 conv (conv3 -> the next Bottleneck's conv1)
+            tail += f",+1x1:{targs[10]}"
+        return f"conv_stream_f16<{32 * tm * mw}x{32 * tn * nw},k{64 * np_}" + tail + ">"
     # conv_stream_f32<TM, TN, MW, NW, NP, NSLOT, HAS_RES, DUAL, HALF>: 32-channel pieces
     m = re.match(r"(?:void )?(?:hmv::)?conv_stream_f32<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, (true|false)(?:, (true|false))?(?:, (?:true|false))?>", name)
     if m:
         tm, tn, mw, nw, np_ = (int(m.group(i)) for i in range(1, 6))
         tail = ",res>" if m.group(6) == "true" else (",dual>" if m.group(7) == "true" else ">")
         return f"conv_stream_f32<{32 * tm * mw}x{32 * tn * nw},k{32 * np_}" + tail
-    # conv_hs_f16<R, S, CPP, TM, TN, MW, NW, NSLOT, HAS_RES>: CPP 16-byte chunks (8 channels each) per pixel; 40-channel layers keep 40 outputs
-    m = re.match(r"(?:void )?(?:hmv::)?conv_hs_f16<(\d+), (\d+), (\d+), \d+, (\d+), \d+, (\d+), \d+, (true|false)>", name)
+    # conv_hs_f16<R, S, CPP, TM, TN, MW, NW, NSLOT, HAS_RES, POOL>: CPP 16-byte chunks (8 channels each) per pixel; 40-channel layers keep 40 outputs
+    m = re.match(r"(?:void )?(?:hmv::)?conv_hs_f16<(\d+), (\d+), (\d+), \d+, (\d+), \d+, (\d+), \d+, (true|false)(?:, (true|false))?>", name)
     if m:
         r_, s_, cpp, tn, nw = (int(m.group(i)) for i in range(1, 6))
         cout = 40 if cpp == 5 else (80 if cpp == 10 else 32 * tn * nw)   # 40- / 80-channel layers run on 64 / 96 weight rows
-        return f"conv_hs_f16<{r_}x{s_},{8 * cpp}->{cout}" + (",res>" if m.group(6) == "true" else ">")
+        return f"conv_hs_f16<{r_}x{s_},{8 * cpp}->{cout}" + (",res" if m.group(6) == "true" else "") + (",+maxpool>" if m.group(7) == "true" else ">")
     m = re.match(r"(?:void )?(?:hmv::)?conv_rds_f32<(\d+), (true|false), \d+>", name)
     if m:
         return f"conv_rds_f32<3x3,{m.group(1)}->{m.group(1)}" + (",res>" if m.group(2) == "true" else ">")

@@ -118,7 +118,10 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- halo DMA roles, block-invariant: pass i moves 16-byte unit L = 512 i + tid of the image = chunk L % CPP of halo pixel
-    // L / CPP (with 128-byte pixels the chunk it FETCHES is XOR-swizzled so that the lane-linear LDS image is conflict-free)
+    // L / CPP (with 128-byte pixels the chunk it FETCHES is XOR-swizzled by the pixel's COLUMN: the 16 lanes of a ds_read_b128 group
+    // read 16 consecutive columns of two image rows -- every (column parity, chunk ^ key) pair once, no bank conflict -- and the key of
+    // a tap's fragment depends on the tap's column offset only, so a fragment address is one block-invariant base per (pixel block,
+    // column offset), one XOR for the chunk pair and an immediate for the tap's row)
     // row << 24 | column << 16 | element offset of (column, source chunk) inside an image row (lda == Cin == 8 CPP: conv_hs_supported);
     // units past the halo get row 200: always out of the image -> zero page
     int hyx[HP];
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
         const int L = NT * i + tid, hp = L / CPP, ch = L - hp * CPP;
         const int hx = hp - (hp / HW) * HW;
         static_assert(8 * (HW * CPP + CPP) < 65536, "column offset field");
-        hyx[i] = ((hp < HROWS ? hp / HW : 200) << 24) | (hx << 16) | (8 * (hx * CPP + (SWZ ? (ch ^ ((hp >> 1) & 7)) : ch)));
+        hyx[i] = ((hp < HROWS ? hp / HW : 200) << 24) | (hx << 16) | (8 * (hx * CPP + (SWZ ? (ch ^ ((hx >> 1) & 7)) : ch)));
     }
 
     auto block_origin = [&](int tt, int &n, int &by, int &bx) {
@@ -236,35 +239,51 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
             const int oA = (tA / S) * HW + tA % S, oB = (tB / S) * HW + tB % S;   // halo pixel offset of the tap
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                if constexpr (SWZ) {   // CPP == 8: both chunks belong to one tap
-                    const int h = hb[a] + hz + oA;
-                    px[a] = *reinterpret_cast<const hf16x8 *>(himg + (h * 8 + ((cA + kh) ^ ((h >> 1) & 7))) * 16);
-                } else {
-                    const int u = (hb[a] + hz) * CPP + (kh ? oB * CPP + cB : oA * CPP + cA);
-                    px[a] = *reinterpret_cast<const hf16x8 *>(himg + u * 16);
-                }
+                static_assert(!SWZ || CPP % 2 == 0, "swizzled pixels take the pipelined loop below");
+                const int u = (hb[a] + hz) * CPP + (kh ? oB * CPP + cB : oA * CPP + cA);
+                px[a] = *reinterpret_cast<const hf16x8 *>(himg + u * 16);
             }
         };
         // One wave per SIMD (the three-wave variant) has nobody to hide an LDS round trip behind.  Its fragments of step Q + 1 are
         // requested BEFORE the MFMAs of step Q, into the other of two register sets, and waited for with a COUNTED lgkmcnt: the
         // reads are inline asm (the compiler, left to track them, reuses one register set and drains the LDS queue before every MFMA
         // group -- 3x the MFMA time), the wait names the registers it releases so that no MFMA can move above it.
-        constexpr bool PIPE = !SWZ && CPP % 2 == 0;
+        constexpr bool PIPE = CPP % 2 == 0;
         hf16x8 pxs[2][TM];
         if constexpr (PIPE) {
             // an even CPP keeps the two chunks of a k16 step inside one tap: lanes 32-63 read 16 bytes behind lanes 0-31, and the
             // step's own displacement is an instruction immediate -- four address registers per block, no per-step arithmetic
-            static_assert(!SWZ && CPP % 2 == 0 && NCH % 2 == 0, "the pipelined variant: unswizzled pixels, whole chunk pairs per tap");
-            unsigned vb[TM];
+            static_assert(CPP % 2 == 0 && NCH % 2 == 0, "the pipelined variant: whole chunk pairs per tap");
+            // unswizzled: one base per pixel block, the whole displacement an immediate.  Swizzled (128-byte pixels): one base per (pixel
+            // block, tap column s) holding the lane's key (kh ^ column key) in its chunk field; chunk pair q XORs bit 5 / 6, the tap row is the immediate
+            constexpr int NB = SWZ ? S : 1;
+            unsigned vb[NB][TM];
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
-                vb[a] = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)himg + (unsigned)(((hb[a] + hz) * CPP + kh) * 16);
-            auto load_asm = [](auto Qc, hf16x8 (&px)[TM], const unsigned (&vbr)[TM]) {
+            for (int sx = 0; sx < NB; ++sx)
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    if constexpr (SWZ)
+                        vb[sx][a] = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)himg +
+                                    (unsigned)(((hb[a] + hz + sx) * 8 + (kh ^ ((((l31 & 15) + sx) >> 1) & 7))) * 16);
+                    else
+                        vb[sx][a] = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)himg + (unsigned)(((hb[a] + hz) * CPP + kh) * 16);
+                }
+            auto load_asm = [](auto Qc, hf16x8 (&px)[TM], const unsigned (&vbr)[NB][TM]) {
                 constexpr int Q = decltype(Qc)::value, tA = (2 * Q) / CPP, cA = 2 * Q - tA * CPP;
-                constexpr int off = (((tA / S) * HW + tA % S) * CPP + cA) * 16;
-                static_assert(off < 65536, "ds_read offset field");
+                if constexpr (SWZ) {
+                    constexpr int off = (tA / S) * HW * 128;
+                    static_assert(off < 65536 && CPP == 8, "ds_read offset field");
 #pragma unroll
-                for (int a = 0; a < TM; ++a) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(px[a]) : "v"(vbr[a]), "n"(off));
+                    for (int a = 0; a < TM; ++a) {
+                        const unsigned ad = vbr[tA % S][a] ^ (unsigned)(cA * 16);
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(px[a]) : "v"(ad), "n"(off));
+                    }
+                } else {
+                    constexpr int off = (((tA / S) * HW + tA % S) * CPP + cA) * 16;
+                    static_assert(off < 65536, "ds_read offset field");
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(px[a]) : "v"(vbr[0][a]), "n"(off));
+                }
             };
             load_asm(std::integral_constant<int, 0>{}, pxs[0], vb);
             hs_static_for<NSTEP>([&](auto Qc) {

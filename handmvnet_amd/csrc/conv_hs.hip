@@ -248,15 +248,20 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
         // requested BEFORE the MFMAs of step Q, into the other of two register sets, and waited for with a COUNTED lgkmcnt: the
         // reads are inline asm (the compiler, left to track them, reuses one register set and drains the LDS queue before every MFMA
         // group -- 3x the MFMA time), the wait names the registers it releases so that no MFMA can move above it.
-        constexpr bool PIPE = CPP % 2 == 0;
+        constexpr bool PIPE = true;
         hf16x8 pxs[2][TM];
         if constexpr (PIPE) {
             // an even CPP keeps the two chunks of a k16 step inside one tap: lanes 32-63 read 16 bytes behind lanes 0-31, and the
             // step's own displacement is an instruction immediate -- four address registers per block, no per-step arithmetic
-            static_assert(CPP % 2 == 0 && NCH % 2 == 0, "the pipelined variant: whole chunk pairs per tap");
+            // An odd CPP (HRNet-w40's 40-channel pixels) puts the two chunks of some k16 steps into two taps.  Inside an image row the next
+            // tap is the next pixel, i.e. the next 16 bytes, as inside a tap; only where the tap sequence changes to the next image row do
+            // lanes 32-63 read DROW bytes behind lanes 0-31 instead of 16: those steps (one, for 3x3 x 5 chunks) take a second base
+            constexpr bool ODD = CPP % 2 == 1;
+            constexpr int DROW = (HW * CPP - ((S - 1) * CPP + CPP - 1)) * 16;
+            static_assert(!ODD || !SWZ, "odd chunk counts: unswizzled pixels");
             // unswizzled: one base per pixel block, the whole displacement an immediate.  Swizzled (128-byte pixels): one base per (pixel
             // block, tap column s) holding the lane's key (kh ^ column key) in its chunk field; chunk pair q XORs bit 5 / 6, the tap row is the immediate
-            constexpr int NB = SWZ ? S : 1;
+            constexpr int NB = SWZ ? S : (ODD ? 2 : 1);
             unsigned vb[NB][TM];
 #pragma unroll
             for (int sx = 0; sx < NB; ++sx)
@@ -266,7 +271,8 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
                         vb[sx][a] = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)himg +
                                     (unsigned)(((hb[a] + hz + sx) * 8 + (kh ^ ((((l31 & 15) + sx) >> 1) & 7))) * 16);
                     else
-                        vb[sx][a] = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)himg + (unsigned)(((hb[a] + hz) * CPP + kh) * 16);
+                        vb[sx][a] = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)himg +
+                                    (unsigned)((hb[a] + hz) * CPP * 16 + kh * (sx ? DROW : 16));
                 }
             auto load_asm = [](auto Qc, hf16x8 (&px)[TM], const unsigned (&vbr)[NB][TM]) {
                 constexpr int Q = decltype(Qc)::value, tA = (2 * Q) / CPP, cA = 2 * Q - tA * CPP;
@@ -280,9 +286,12 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
                     }
                 } else {
                     constexpr int off = (((tA / S) * HW + tA % S) * CPP + cA) * 16;
-                    static_assert(off < 65536, "ds_read offset field");
+                    // lanes 32-63: chunk 2 Q + 1 (past the reduction's end it multiplies zero weights: the 16 bytes behind the last chunk,
+                    // inside the slot's zero-filled padding, do)
+                    constexpr bool strad = ODD && cA == CPP - 1 && tA % S == S - 1 && 2 * Q + 1 < NCH;
+                    static_assert(off + (strad ? DROW : 16) + 16 <= SLOT && off < 65536, "inside the halo slot; ds_read offset field");
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(px[a]) : "v"(vbr[0][a]), "n"(off));
+                    for (int a = 0; a < TM; ++a) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(px[a]) : "v"(vbr[strad ? 1 : 0][a]), "n"(off));
                 }
             };
             load_asm(std::integral_constant<int, 0>{}, pxs[0], vb);

@@ -19,3 +19,8 @@ run bench_hr40_f32x3 --workload hr40 --dtype f32x3 --no-cpu-baseline --steps 6 -
 HMV_BENCH_SAME_DEVICE=1 HMV_BENCH_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_2rank_rehearsal.json 2> $O/bench_2rank_rehearsal.err || { echo "FAILED 2rank"; tail -5 $O/bench_2rank_rehearsal.err; exit 71; }
 python -c "
 import json; d=json.load(open('$O/bench_2rank_rehearsal.json')); print('2rank', d['ms_per_step'], d['value'], d['n_gpus'], d['communicator'])"
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/tests.log 2>&1; rc=$?
+tail -4 $O/tests.log
+[ $rc -eq 0 ] || exit $rc
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 || { tail -20 $O/smoke.log; exit 72; }
+tail -2 $O/smoke.log

@@ -551,8 +551,11 @@ def test_full_size_properties(mode):
     assert cam <= (fp16_bounds("cfg3s_r50_v8_256")["joints_cam"] if mode == "f16" else TOL_CAM), (mode, cam)
 
 
-@pytest.mark.parametrize("case,frames_per_sample,fewer", [("cfg3s_r50_v8_256", 8, 4), ("hr40_v4_128", 4, 3)])
-def test_chained_launches_give_the_bits_of_one_launch_per_conv(case, frames_per_sample, fewer):
+@pytest.mark.parametrize("case,frames_per_sample,fewer,size,samples", [("cfg3s_r50_v8_256", 8, 4, 256, (4, 5)), ("hr40_v4_128", 4, 3, 256, (8, 9)),
+                                                                       # 128 x 128 frames: 32 x 32 pooled maps = 5 x 5 ragged pooled blocks, partial last pixel tiles;
+                                                                       # 96 x 96: only the pooled stem is large enough (24 x 24 pooled = 4 x 4 ragged blocks)
+                                                                       ("cfg3s_r50_v8_256", 8, 4, 128, (16, 17)), ("cfg3s_r50_v8_256", 8, 1, 96, (9,))])
+def test_chained_launches_give_the_bits_of_one_launch_per_conv(case, frames_per_sample, fewer, size, samples):
     """Cross-layer launches of the fp16 backbone at large batches.  conv_stream.hip "chain": a layer1 Bottleneck's conv3 launch also
     computes the NEXT block's conv1 from its output tile in LDS (resnet.py:124-144 / 128-130; three launches fewer, the 256-channel
     tensor read once less per block).  conv_hs.hip "+maxpool": the stem conv's epilogue applies the 3x3 / 2 max pool to its block in
@@ -567,8 +570,8 @@ def test_chained_launches_give_the_bits_of_one_launch_per_conv(case, frames_per_
     m.load_state_dict(sd)
     m.half()
     dev = torch.device("cuda:0")
-    for nb in (32 // frames_per_sample, 32 // frames_per_sample + 1):
-        x, bbox, intr = synth_inputs(cfg, nb, 7 + nb, 256)
+    for nb in samples:
+        x, bbox, intr = synth_inputs(cfg, nb, 7 + nb, size)
         m.set_chain_fusion(True)
         chained = _run(m, x, bbox, intr)
         n_chained = m.launch_count()

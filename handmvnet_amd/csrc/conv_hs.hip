@@ -342,9 +342,19 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
+                        // relu(acc * 1 + 0) -> fp16 as round-then-clamp on packed halves: the same bits for every input (a pooled launch
+                        // has ReLU and unscaled weights: conv_hs_supported), 1 instead of 2.5 vector instructions per output -- this kernel
+                        // is bound by instruction issue, not by the matrix pipe
                         hf16x8 hv;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + 0.f, lo);
+                        for (int u = 0; u < 8; ++u) hv[u] = (_Float16)acc[a][b][8 * j + u];
+                        {
+                            typedef unsigned hu32x4 __attribute__((ext_vector_type(4)));
+                            hu32x4 w = __builtin_bit_cast(hu32x4, hv);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) asm("v_pk_max_f16 %0, %1, 0" : "=v"(w[u]) : "v"(w[u]));
+                            hv = __builtin_bit_cast(hf16x8, w);
+                        }
                         const unsigned ad = tile + (unsigned)(pxl * 128 + ((((n0 >> 3) + 4 * b + 2 * j + kh) ^ (pxl & 7)) * 16));
                         asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(hv) : "memory");
                     }
@@ -354,27 +364,32 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
             const int pp = tid >> 3, c8 = tid & 7, py = pp / 7, pxx = pp - 7 * py;
             const int gy = 7 * by + py, gx = 7 * bx + pxx;
             hf16x8 m;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) m[u] = (_Float16)(-65504.f);
             {   // all nine window vectors are requested at once (every window lies inside the tile; threads past the 49 pooled pixels
-                // read pixel 0 and store to the trash page); positions outside the conv map count as the smallest fp16, as in the pool kernel
+                // read pixel 0 and store to the trash page).  A window position outside the conv map does not count (the pool kernel
+                // skips it): with even map sizes (conv_hs_supported) the only such positions of a pooled pixel that is KEPT are conv row
+                // / column -1 -- the first row / column of the first block's tile -- and reading the window's middle row / column a second
+                // time instead leaves the maximum unchanged.  v_pk_max_f16 directly: the builtin canonicalises both operands first
                 const int py_ = pp < 49 ? py : 0, px_ = pp < 49 ? pxx : 0;
-                hf16x8 wv[3][3];
+                const int r0 = 2 * py_ + ((by == 0 && py_ == 0) ? 1 : 0), c0 = 2 * px_ + ((bx == 0 && px_ == 0) ? 1 : 0);
+                typedef unsigned hu32x4 __attribute__((ext_vector_type(4)));
+                hu32x4 wv[3][3];
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        const int pl = (2 * py_ + r) * 16 + 2 * px_ + q;
-                        wv[r][q] = *reinterpret_cast<const hf16x8 *>(zones + pl * 128 + ((c8 ^ (pl & 7)) * 16));
+                        const int pl = (r == 0 ? r0 : 2 * py_ + r) * 16 + (q == 0 ? c0 : 2 * px_ + q);
+                        wv[r][q] = *reinterpret_cast<const hu32x4 *>(zones + pl * 128 + ((c8 ^ (pl & 7)) * 16));
                     }
-                const hf16x8 lowest = m;
+                hu32x4 mw_ = wv[0][0];
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const bool in = (unsigned)(14 * by - 1 + 2 * py_ + r) < (unsigned)p.Ho && (unsigned)(14 * bx - 1 + 2 * px_ + q) < (unsigned)p.Wo;
-                        m = __builtin_elementwise_max(m, in ? wv[r][q] : lowest);
-                    }
+                    for (int q = 0; q < 3; ++q)
+                        if (r | q) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) asm("v_pk_max_f16 %0, %1, %2" : "=v"(mw_[u]) : "v"(mw_[u]), "v"(wv[r][q][u]));
+                        }
+                m = __builtin_bit_cast(hf16x8, mw_);
             }
             _Float16 *dst = (pp < 49 && gy < p.pool_h && gx < p.pool_w) ? Out + ((size_t)(n * p.pool_h + gy) * p.pool_w + gx) * p.ldc + 8 * c8 : trash;
             asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(m) : "memory");
@@ -566,7 +581,7 @@ bool conv_hs_supported(const ConvParams &p) {
     if (p.pool) {   // conv + ReLU + MaxPool2d(3, 2, 1) in one launch: the fp16 stem only, at least four 7 x 7 pooled blocks per workgroup
         static const bool nopool = getenv("HMV_NO_STEMPOOL") != nullptr;   // development knob (A/B runs)
         if (nopool || hs_kind(p) != 2 || !p.in_f16 || !p.out_f16 || p.res || p.fill || p.act != ACT_RELU) return false;
-        if (p.pool_h != (p.Ho + 2 - 3) / 2 + 1 || p.pool_w != (p.Wo + 2 - 3) / 2 + 1 || p.ldc != 64) return false;
+        if (p.pool_h != (p.Ho + 2 - 3) / 2 + 1 || p.pool_w != (p.Wo + 2 - 3) / 2 + 1 || p.ldc != 64 || (p.Ho & 1) || (p.Wo & 1) || p.acc_shift) return false;
         if (g_hs_mode <= 0 && (long long)p.N * ((p.pool_h + 6) / 7) * ((p.pool_w + 6) / 7) < 4 * 256) return false;
     }
     if (hs_stem32(p)) {

@@ -1,5 +1,5 @@
 # what the driver runs at round end: the GPU suite, smoke(), the default bench line
-O=gpurun_out/r02check; mkdir -p $O
+O=gpurun_out/r03check; mkdir -p $O
 python -m pytest tests -x -q -m gpu > $O/tests.log 2>&1; rc=$?
 tail -4 $O/tests.log
 [ $rc -eq 0 ] || exit $rc

@@ -174,6 +174,9 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
     const int fsw = (l31 >> 1) & 7;
 
     // issue the pixel DMAs of piece G (in this workgroup's own piece sequence; outside [0, ntl * NP) -> zero page)
+    // DUAL: element offset of this thread's pixel rows in the second source, computed at the FIRST piece of a tile that reads it and kept
+    // for the tile's later ones (pieces go out in order; two integer divisions per row and piece otherwise: the k384 launch was bound by them)
+    size_t off2[DUAL ? PA : 1] = {};
     auto issue_A = [&](int G) {
         const int tt = G >= 0 ? G / NP : -1, jj = G >= 0 ? G - tt * NP : 0, slot = G & (NSLOT - 1);
         const int mt = stream + tt * nstreams;
@@ -183,10 +186,12 @@ __global__ __launch_bounds__(64 * MW *NW, (MW * NW) / 4) void conv_stream_f16(co
             const bool ok = tt >= 0 && tt < ntl && m < p.M;
             const _Float16 *src = zero16;
             if constexpr (DUAL) {
-                if (ok && jj * 64 >= p.ksplit) {
+                if (jj * 64 == p.ksplit) {   // (wave-uniform)
                     const int hw = p.Ho * p.Wo, n = m / hw, rem = m - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                    src = reinterpret_cast<const _Float16 *>(p.in2) + ((size_t)(n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.lda2 +
-                          (jj * 64 - p.ksplit) + 8 * kqs;
+                    off2[i] = ((size_t)(n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.lda2 + 8 * kqs;
+                }
+                if (ok && jj * 64 >= p.ksplit) {
+                    src = reinterpret_cast<const _Float16 *>(p.in2) + off2[i] + (jj * 64 - p.ksplit);
                 } else if (ok) {
                     src = Ain + (size_t)m * p.lda + jj * 64 + 8 * kqs;
                 }

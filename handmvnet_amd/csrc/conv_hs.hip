@@ -69,7 +69,7 @@ constexpr int hs_after_residual(int HP, int RB, int OS) { return OS + HP + RB; }
 // fp16 values, so the pooled map is BIT-IDENTICAL to conv + pool as two launches -- and store ONE 16-byte vector each.  The conv map
 // (8x the pooled map's bytes) is never written or read; 1.3x the conv FLOPs are recomputed on a kernel that is nowhere near MFMA-bound.
 template <int R, int S, int CPP, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES, bool POOL = false>
-__global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f16(const ConvParams p) {
+__global__ __launch_bounds__(64 * MW * NW, ((MW * NW > 4 || POOL) ? 2 : 1)) void conv_hs_f16(const ConvParams p) {
     constexpr int NWV = MW * NW, NT = 64 * NWV;
     constexpr int BH = 2 * MW * TM;                    // output rows of a block
     constexpr int HH = BH + R - 1, HW = 16 + S - 1, HROWS = HH * HW;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
     constexpr int HP = (HROWS * CPP + NT - 1) / NT;    // DMA instructions per halo image and thread
     constexpr int SLOT = HP * NT * 16;                 // bytes of one halo image (padded to whole passes)
     constexpr int D = NSLOT - 1;
-    constexpr int RB = HAS_RES ? TM * TN * 2 : 0, OS = POOL ? 1 : TM * TN * 2;
-    static_assert(!POOL || (!HAS_RES && BH == 16 && NT == 512 && TN * NW == 2), "pooled epilogue: 16 x 16 blocks of 64 channels, eight waves");
+    constexpr int RB = HAS_RES ? TM * TN * 2 : 0, OS = POOL ? 512 / NT : TM * TN * 2;
+    static_assert(!POOL || (!HAS_RES && BH == 16 && (NT == 512 || NT == 256) && TN * NW == 2), "pooled epilogue: 16 x 16 blocks of 64 channels, 512 pooling tasks");
     constexpr int ZW = TM * TN * 2 * 1024;
     constexpr int NSTEP = (NCH + 1) / 2;
     constexpr bool SWZ = CPP == 8;                     // 128-byte pixels: XOR swizzle; 80- / 32-byte pixels are conflict-free as they lie
@@ -360,8 +360,11 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
                     }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            // pooled pixel (py, px) of the block x 8 channels per thread; window rows 2 py .. 2 py + 2 of the tile = conv rows 14 by - 1 + ..
-            const int pp = tid >> 3, c8 = tid & 7, py = pp / 7, pxx = pp - 7 * py;
+            // pooled pixel (py, px) of the block x 8 channels per task (512 / NT per thread); window rows 2 py .. 2 py + 2 of the tile = conv rows 14 by - 1 + ..
+#pragma unroll
+            for (int task0 = 0; task0 < 512; task0 += NT) {
+            const int task = task0 + tid;
+            const int pp = task >> 3, c8 = task & 7, py = pp / 7, pxx = pp - 7 * py;
             const int gy = 7 * by + py, gx = 7 * bx + pxx;
             hf16x8 m;
             {   // all nine window vectors are requested at once (every window lies inside the tile; threads past the 49 pooled pixels
@@ -393,6 +396,7 @@ __global__ __launch_bounds__(64 * MW * NW, (MW * NW > 4 ? 2 : 1)) void conv_hs_f
             }
             _Float16 *dst = (pp < 49 && gy < p.pool_h && gx < p.pool_w) ? Out + ((size_t)(n * p.pool_h + gy) * p.pool_w + gx) * p.ldc + 8 * c8 : trash;
             asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(m) : "memory");
+            }
         } else {
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
@@ -622,7 +626,8 @@ static hipError_t launch_hs_one(const ConvParams &p, hipStream_t s) {
         configured[dev] = true;
     }
     const int nblk = POOL ? p.N * ((p.pool_h + 6) / 7) * ((p.pool_w + 6) / 7) : p.N * (p.H / BH) * (p.W >> 4);
-    hipLaunchKernelGGL(kern, dim3(nblk < 256 ? nblk : 256), dim3(NT), lds, s, p);
+    const int cap = (POOL && NT == 256) ? 512 : 256;   // four-wave pooled workgroups: two per CU
+    hipLaunchKernelGGL(kern, dim3(nblk < cap ? nblk : cap), dim3(NT), lds, s, p);
     return hipGetLastError();
 }
 
@@ -664,7 +669,11 @@ hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name)
             }
             if (p.pool) {
                 if (name) *name = "conv_hs_f16<4x4,16->64,+maxpool>";
-                return launch_hs_one<4, 4, 2, 1, 2, 8, 1, 4, false, true>(p, s);
+                // two FOUR-wave workgroups per CU (each wave four pixel rows x 64 channels; 68 KB of LDS each): they drift apart, and one's
+                // epilogue + pooling (vector instructions) runs under the other's MFMAs.  HMV_STEM_POOL8=1: one eight-wave workgroup (A/B runs)
+                static const bool pool8 = getenv("HMV_STEM_POOL8") != nullptr;
+                if (pool8) return launch_hs_one<4, 4, 2, 1, 2, 8, 1, 4, false, true>(p, s);
+                return launch_hs_one<4, 4, 2, 2, 2, 4, 1, 3, false, true>(p, s);
             }
             if (name) *name = "conv_hs_f16<4x4,16->64>";
             return launch_hs_one<4, 4, 2, 1, 2, 8, 1, 4, false>(p, s);

@@ -69,7 +69,7 @@ constexpr int hs_after_residual(int HP, int RB, int OS) { return OS + HP + RB; }
 // fp16 values, so the pooled map is BIT-IDENTICAL to conv + pool as two launches -- and store ONE 16-byte vector each.  The conv map
 // (8x the pooled map's bytes) is never written or read; 1.3x the conv FLOPs are recomputed on a kernel that is nowhere near MFMA-bound.
 template <int R, int S, int CPP, int TM, int TN, int MW, int NW, int NSLOT, bool HAS_RES, bool POOL = false>
-__global__ __launch_bounds__(64 * MW * NW, ((MW * NW > 4 || POOL) ? 2 : 1)) void conv_hs_f16(const ConvParams p) {
+__global__ __launch_bounds__(64 * MW * NW, ((MW * NW >= 4) ? 2 : 1)) void conv_hs_f16(const ConvParams p) {
     constexpr int NWV = MW * NW, NT = 64 * NWV;
     constexpr int BH = 2 * MW * TM;                    // output rows of a block
     constexpr int HH = BH + R - 1, HW = 16 + S - 1, HROWS = HH * HW;
@@ -565,7 +565,8 @@ void conv_hs_set_mode(int mode) { g_hs_mode = mode; }
 // 0: no instantiation; 1: 3x3 pad 1, 64 -> 64 channels; 2: the 4x4 space-to-depth stem, 16 -> 64 channels; 3 / 4: 3x3 pad 1, 40 -> 40 /
 // 80 -> 80 channels in the plain (r, s, c) K order (HRNet-w40's two highest-resolution branches, hrnet.py:96-221; kind 4 on 8 x 16
 // blocks under three waves)
-static int hs_bh(int kind) { return kind == 4 ? 8 : 16; }
+static bool hs_wave8() { static const bool v = getenv("HMV_HS_8WAVE") != nullptr; return v; }   // development knob (A/B runs)
+static int hs_bh(int kind) { return kind == 4 ? 8 : 16; }   // (the size rule counts 16-row blocks for kinds 1 - 3 whatever form runs)
 static int hs_kind(const ConvParams &p) {
     if (p.R == 3 && p.S == 3 && p.pad_h == 1 && p.pad_w == 1 && p.Cin == 64 && p.Cout == 64 && p.Kpad == 576) return 1;
     if (p.R == 4 && p.S == 4 && p.pad_h == 2 && p.pad_w == 2 && p.Cin == 16 && p.Cout == 64 && p.Kpad == 256 && !p.res) return 2;
@@ -626,7 +627,7 @@ static hipError_t launch_hs_one(const ConvParams &p, hipStream_t s) {
         configured[dev] = true;
     }
     const int nblk = POOL ? p.N * ((p.pool_h + 6) / 7) * ((p.pool_w + 6) / 7) : p.N * (p.H / BH) * (p.W >> 4);
-    const int cap = (POOL && NT == 256) ? 512 : 256;   // four-wave pooled workgroups: two per CU
+    const int cap = NT == 256 ? 512 : 256;   // four-wave workgroups: two per CU
     hipLaunchKernelGGL(kern, dim3(nblk < cap ? nblk : cap), dim3(NT), lds, s, p);
     return hipGetLastError();
 }
@@ -650,12 +651,16 @@ hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name)
     }
     switch (hs_kind(p)) {
         case 1:
+            // two FOUR-wave workgroups per CU on 8 x 16 blocks (2 x 2 waves; 24 KB halo images): they drift apart, and one's halo wait
+            // and epilogue run under the other's MFMAs (the pooled stem gained 24 % that way).  HMV_HS_8WAVE=1: the eight-wave 16 x 16 form
             if (p.res) {
                 if (name) *name = "conv_hs_f16<3x3,64->64,res>";
-                return launch_hs_one<3, 3, 8, 2, 1, 4, 2, 2, true>(p, s);
+                if (hs_wave8()) return launch_hs_one<3, 3, 8, 2, 1, 4, 2, 2, true>(p, s);
+                return launch_hs_one<3, 3, 8, 2, 1, 2, 2, 2, true>(p, s);
             }
             if (name) *name = "conv_hs_f16<3x3,64->64>";
-            return launch_hs_one<3, 3, 8, 2, 1, 4, 2, 3, false>(p, s);   // no landing zones: three halo images (two in flight)
+            if (hs_wave8()) return launch_hs_one<3, 3, 8, 2, 1, 4, 2, 3, false>(p, s);   // no landing zones: three halo images (two in flight)
+            return launch_hs_one<3, 3, 8, 2, 1, 2, 2, 3, false>(p, s);
         case 2:
             // eight waves along the pixels, both 32-channel blocks per wave (128 weight registers): every pixel fragment read from LDS
             // feeds TWO MFMAs.  With one block per wave (4 x 2 waves) a k16 step is one 1 KB LDS read per 32-cycle MFMA on every SIMD --
@@ -677,13 +682,15 @@ hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name)
             }
             if (name) *name = "conv_hs_f16<4x4,16->64>";
             return launch_hs_one<4, 4, 2, 1, 2, 8, 1, 4, false>(p, s);
-        case 3:   // 40-channel pixels: 26 KB halo images
+        case 3:   // 40-channel pixels: 26 KB halo images (16 KB for the four-wave form's 8 x 16 blocks)
             if (p.res) {
                 if (name) *name = "conv_hs_f16<3x3,40->40,res>";
-                return launch_hs_one<3, 3, 5, 2, 1, 4, 2, 3, true>(p, s);
+                if (hs_wave8()) return launch_hs_one<3, 3, 5, 2, 1, 4, 2, 3, true>(p, s);
+                return launch_hs_one<3, 3, 5, 2, 1, 2, 2, 3, true>(p, s);
             }
             if (name) *name = "conv_hs_f16<3x3,40->40>";
-            return launch_hs_one<3, 3, 5, 2, 1, 4, 2, 4, false>(p, s);
+            if (hs_wave8()) return launch_hs_one<3, 3, 5, 2, 1, 4, 2, 4, false>(p, s);
+            return launch_hs_one<3, 3, 5, 2, 1, 2, 2, 4, false>(p, s);
         case 4:   // 80-channel pixels, 96 weight rows on three channel waves (one per SIMD, up to 512 registers each): 8 x 16 blocks, 30 KB halo images
             if (p.res) {
                 if (name) *name = "conv_hs_f16<3x3,80->80,res>";

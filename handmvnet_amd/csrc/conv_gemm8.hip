@@ -432,16 +432,20 @@ void conv_gemm8_set_mode(int mode) { g_gemm8_mode = mode; }
 
 bool conv_gemm8_supported(const ConvParams &p) {
     static int off = -1;   // development knob: HMV_NO_GEMM8=1 keeps these convs on conv_igemm (A/B runs)
-    if (off < 0) off = getenv("HMV_NO_GEMM8") ? 1 : 0;
+    if (off < 0) off = HMV_DEV_ENV("HMV_NO_GEMM8") ? 1 : 0;
     if (g_gemm8_mode == 0 || (g_gemm8_mode < 0 && off)) return false;
     if (!p.in_f16 || !p.out_f16 || p.res || p.R != 1 || p.S != 1 || p.pad_h || p.pad_w || p.up || p.ksl > 1 || p.phases > 1) return false;
     if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out) return false;
     if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
     if (p.Kpad % 64 || p.Kpad < 128 || (p.ldc & 7) || ((p.lda ? p.lda : p.Cin) & 7) || ((p.ldw ? p.ldw : p.Kpad) & 7)) return false;
+    // the loop walks Kpad / 64 k-steps and DMA-reads Kpad halfs per pixel row with no column mask: every reduction column must be a real
+    // channel of its source (a padded K would read the next pixel's channels against zero weights: 0 x NaN, and past the buffer's end)
+    if (p.K != p.Kpad) return false;
     if (p.in2) {
+        if (p.ksplit > (p.lda ? p.lda : p.Cin) || p.Kpad - p.ksplit > p.lda2) return false;
         if (p.ksplit % 64 || p.ksplit <= 0 || p.ksplit >= p.Kpad || (p.lda2 & 7) || p.stride != 1) return false;
         if ((long long)p.N * p.H2 * p.W2 * p.lda2 >= (1ll << 31)) return false;
-    } else if (p.stride != 1) {
+    } else if (p.stride != 1 || p.Cin != p.Kpad) {
         return false;
     }
     if ((long long)p.M * (p.lda ? p.lda : p.Cin) >= (1ll << 31)) return false;   // 32-bit element offsets of the pixel rows
@@ -467,7 +471,7 @@ hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name) {
     // development knob, OFF by default: HMV_GEMM8_RING=1 selects conv_gemm8r_f16 (wave-specialised operand streams on a k32 ring).
     // Measured 6 % SLOWER than the four-phase loop (layer3 conv1 172 vs 162 us, profiles/r03_probe_gemm8_ring.txt): these launches are
     // bound by power, not by request latency (0.68 MFMA-busy in cycles at a 1.06-1.35 GHz clock on dense operands)
-    static const int ring = getenv("HMV_GEMM8_RING") ? atoi(getenv("HMV_GEMM8_RING")) : 0;
+    static const int ring = HMV_DEV_ENV("HMV_GEMM8_RING") ? atoi(HMV_DEV_ENV("HMV_GEMM8_RING")) : 0;
     if (ring) {
         static bool rconf[64] = {};
         if (!rconf[dev]) {

@@ -565,7 +565,7 @@ void conv_hs_set_mode(int mode) { g_hs_mode = mode; }
 // 0: no instantiation; 1: 3x3 pad 1, 64 -> 64 channels; 2: the 4x4 space-to-depth stem, 16 -> 64 channels; 3 / 4: 3x3 pad 1, 40 -> 40 /
 // 80 -> 80 channels in the plain (r, s, c) K order (HRNet-w40's two highest-resolution branches, hrnet.py:96-221; kind 4 on 8 x 16
 // blocks under three waves)
-static bool hs_wave8() { static const bool v = getenv("HMV_HS_8WAVE") != nullptr; return v; }   // development knob (A/B runs)
+static bool hs_wave8() { static const bool v = HMV_DEV_ENV("HMV_HS_8WAVE") != nullptr; return v; }   // development knob (A/B runs)
 static int hs_bh(int kind) { return kind == 4 ? 8 : 16; }   // (the size rule counts 16-row blocks for kinds 1 - 3 whatever form runs)
 static int hs_kind(const ConvParams &p) {
     if (p.R == 3 && p.S == 3 && p.pad_h == 1 && p.pad_w == 1 && p.Cin == 64 && p.Cout == 64 && p.Kpad == 576) return 1;
@@ -581,16 +581,16 @@ static bool hs_stem32(const ConvParams &p) {
 
 bool conv_hs_supported(const ConvParams &p) {
     static int off = -1;   // development knob: HMV_NO_HS=1 keeps these convs on conv_igemm (A/B runs)
-    if (off < 0) off = getenv("HMV_NO_HS") ? 1 : 0;
+    if (off < 0) off = HMV_DEV_ENV("HMV_NO_HS") ? 1 : 0;
     if (g_hs_mode == 0 || (g_hs_mode < 0 && off)) return false;
     if (p.pool) {   // conv + ReLU + MaxPool2d(3, 2, 1) in one launch: the fp16 stem only, at least four 7 x 7 pooled blocks per workgroup
-        static const bool nopool = getenv("HMV_NO_STEMPOOL") != nullptr;   // development knob (A/B runs)
+        static const bool nopool = HMV_DEV_ENV("HMV_NO_STEMPOOL") != nullptr;   // development knob (A/B runs)
         if (nopool || hs_kind(p) != 2 || !p.in_f16 || !p.out_f16 || p.res || p.fill || p.act != ACT_RELU) return false;
         if (p.pool_h != (p.Ho + 2 - 3) / 2 + 1 || p.pool_w != (p.Wo + 2 - 3) / 2 + 1 || p.ldc != 64 || (p.Ho & 1) || (p.Wo & 1) || p.acc_shift) return false;
         if (g_hs_mode <= 0 && (long long)p.N * ((p.pool_h + 6) / 7) * ((p.pool_w + 6) / 7) < 4 * 256) return false;
     }
     if (hs_stem32(p)) {
-        static const bool off32 = getenv("HMV_NO_HS32") != nullptr;   // development knob (A/B runs)
+        static const bool off32 = HMV_DEV_ENV("HMV_NO_HS32") != nullptr;   // development knob (A/B runs)
         if (off32 && g_hs_mode <= 0) return false;
         if (p.stride != 1 || p.up || p.in2 || p.ksl > 1 || p.phases > 1 || p.Ho != p.H || p.Wo != p.W || (p.H & 15) || (p.W & 15)) return false;
         if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out || p.fill) return false;
@@ -666,7 +666,7 @@ hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name)
             // feeds TWO MFMAs.  With one block per wave (4 x 2 waves) a k16 step is one 1 KB LDS read per 32-cycle MFMA on every SIMD --
             // exactly the LDS peak of the CU (128 B / clk), and the kernel ran at 0.34 MFMA-busy
             {
-                static const bool old_split = getenv("HMV_STEM_4x2") != nullptr;   // development knob (A/B runs): the round-3 wave split
+                static const bool old_split = HMV_DEV_ENV("HMV_STEM_4x2") != nullptr;   // development knob (A/B runs): the round-3 wave split
                 if (old_split && !p.pool) {
                     if (name) *name = "conv_hs_f16<4x4,16->64>";
                     return launch_hs_one<4, 4, 2, 2, 1, 4, 2, 4, false>(p, s);
@@ -676,7 +676,7 @@ hipError_t launch_conv_hs(const ConvParams &p, hipStream_t s, const char **name)
                 if (name) *name = "conv_hs_f16<4x4,16->64,+maxpool>";
                 // two FOUR-wave workgroups per CU (each wave four pixel rows x 64 channels; 68 KB of LDS each): they drift apart, and one's
                 // epilogue + pooling (vector instructions) runs under the other's MFMAs.  HMV_STEM_POOL8=1: one eight-wave workgroup (A/B runs)
-                static const bool pool8 = getenv("HMV_STEM_POOL8") != nullptr;
+                static const bool pool8 = HMV_DEV_ENV("HMV_STEM_POOL8") != nullptr;
                 if (pool8) return launch_hs_one<4, 4, 2, 1, 2, 8, 1, 4, false, true>(p, s);
                 return launch_hs_one<4, 4, 2, 2, 2, 4, 1, 3, false, true>(p, s);
             }

@@ -245,7 +245,7 @@ int conv_ht_mode() { return g_ht_mode; }
 // shape rule (the engine asks it at weight-packing time and at launch: the same answer for every batch)
 bool conv_ht_shape_ok(int R, int S, int stride, int pad, int Cin, int Cout, int H, int W) {
     static int off = -1;   // development knob: HMV_NO_HT=1 keeps these layers on conv_igemm's 256 x 256 halo tiles (A/B runs)
-    if (off < 0) off = getenv("HMV_NO_HT") ? 1 : 0;
+    if (off < 0) off = HMV_DEV_ENV("HMV_NO_HT") ? 1 : 0;
     return !off && R == 3 && S == 3 && stride == 1 && pad == 1 && Cin % 32 == 0 && Cin >= 64 && Cout % 128 == 0 && H % 16 == 0 && W % 32 == 0 &&
            H > 0 && W > 0;
 }

@@ -1224,8 +1224,8 @@ bool conv_partial_n(ConvTile t, int Cout) {
 
 ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
     static int forced = -2;   // development knob: HMV_FORCE_TILE=<ConvTile> for layers with Cout > 64
-    if (forced == -2) { const char *e = getenv("HMV_FORCE_TILE"); forced = e ? atoi(e) : -1; }
-    static const bool force_all = getenv("HMV_FORCE_TILE_ALL") != nullptr;   // ... and for the narrow layers too
+    if (forced == -2) { const char *e = HMV_DEV_ENV("HMV_FORCE_TILE"); forced = e ? atoi(e) : -1; }
+    static const bool force_all = HMV_DEV_ENV("HMV_FORCE_TILE_ALL") != nullptr;   // ... and for the narrow layers too
     if ((Cout > 64 || force_all) && forced >= 0 && forced < TILE_COUNT) return (ConvTile)forced;
     // Measured on MI355X (tools/conv_sweep.py): the matrix pipe is DVFS/power limited, so the tile with
     // the least L2->LDS traffic per FLOP wins as long as it still fills the 256 CUs for several rounds.
@@ -1238,7 +1238,7 @@ ConvTile conv_pick_tile(int M, int Cout, int K, bool f16, bool has_res) {
     // its CU, so its 20 us drain overlaps nothing (75 us main loop: 100 TF).  Two 8-wave 256x128 workgroups per CU (k-step 16,
     // 48 KB of tile buffers, <= 128 registers) alternate: one drains while the other computes -- 1.44 -> 1.30 ms per launch
     // although each main loop is less efficient (tools/stagger_probe.py, profiles/r02_probe_w8.txt)
-    static const bool no_w8 = getenv("HMV_NO_W8") != nullptr;   // development knob (A/B runs)
+    static const bool no_w8 = HMV_DEV_ENV("HMV_NO_W8") != nullptr;   // development knob (A/B runs)
     if (!no_w8 && !f16 && has_res && K <= 256 && Cout >= 512 && (long long)((M + 255) / 256) * ((Cout + 127) / 128) >= 2048)
         return TILE_256x128_K16W8;
     // ... and the squeezing conv1 of layer2 (256 / 512 -> 128, no residual): one N-tile, eight k-steps of 32 or sixteen -- the same
@@ -1325,7 +1325,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     {   // development knob: HMV_STAGGER=<10-ns ticks per phase group>[,<blocks of the first round>]
         static int st_ticks = -1, st_blocks = 256, st_mode = 0;
         if (st_ticks < 0) {
-            const char *e = getenv("HMV_STAGGER");
+            const char *e = HMV_DEV_ENV("HMV_STAGGER");
             st_ticks = e ? atoi(e) : 0;
             if (e) { const char *c = strchr(e, ','); if (c) { st_blocks = atoi(c + 1); c = strchr(c + 1, ','); if (c) st_mode = atoi(c + 1); } }
         }
@@ -1333,10 +1333,10 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         p.stagger_blocks = st_blocks;
         p.stagger_mode = st_mode;
         static int pf = -1;   // development knob, OFF by default: HMV_PREFETCH=1 enables the software L2 prefetch (A/B runs)
-        if (pf < 0) { const char *e = getenv("HMV_PREFETCH"); pf = e ? atoi(e) : 0; }
+        if (pf < 0) { const char *e = HMV_DEV_ENV("HMV_PREFETCH"); pf = e ? atoi(e) : 0; }
         p.prefetch = pf;
         static int burst = -1;   // development knob: HMV_BURST=0 keeps the residual on the register-ring path (A/B runs)
-        if (burst < 0) { const char *e = getenv("HMV_BURST"); burst = e ? atoi(e) : 1; }
+        if (burst < 0) { const char *e = HMV_DEV_ENV("HMV_BURST"); burst = e ? atoi(e) : 1; }
         p.burst = burst;
     }
     p.acc_scale = ldexpf(1.f, -p.acc_shift);
@@ -1362,7 +1362,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
             p.x3_plane || p.cwrap || p.rd_cout || p.ksl > 1 || p.phases > 1 || p.up)
             return hipErrorInvalidValue;
         static int ht_min = -1;   // development knob: HMV_HT_MIN_TILES=<n> (default 256: one tile per CU)
-        if (ht_min < 0) { const char *e = getenv("HMV_HT_MIN_TILES"); ht_min = e ? atoi(e) : 256; }
+        if (ht_min < 0) { const char *e = HMV_DEV_ENV("HMV_HT_MIN_TILES"); ht_min = e ? atoi(e) : 256; }
         const long long ht_tiles = (long long)p.N * (p.H >> 4) * (p.W >> 5) * (p.Cout / 128);
         if (conv_ht_mode() > 0 || (conv_ht_mode() < 0 && ht_tiles >= ht_min)) return launch_conv_ht(p, s, name);
         if ((long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) < 256) {
@@ -1431,12 +1431,12 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     // fp16 256x256 (the plain kernels of the backbone) on the four-stage ring main loop (ring_stages above): measured 4-8 %
     // SLOWER than the two-stage loop (profiles/r02_probe_ring.txt), so it stays behind a development knob
     static int ring = -1;   // HMV_F16_RING=1 selects it (A/B runs)
-    if (ring < 0) { const char *e = getenv("HMV_F16_RING"); ring = e ? atoi(e) : 0; }
+    if (ring < 0) { const char *e = HMV_DEV_ENV("HMV_F16_RING"); ring = e ? atoi(e) : 0; }
     if (ring && p.in_f16 && tile == TILE_256x256 && !generic && !dense && !p.x3_plane && !p.cwrap && !p.rd_cout && p.ksl <= 1)
         tile = TILE_256x256_RING;
     // fp16 3x3 stride-1 pad-1 convs on 256 x 256 tiles: 16 x 16 pixel blocks with the halo image in LDS (MODE_HALO)
     static int halo = -1;   // development knob: HMV_NO_HALO=1 keeps the nine-fetch MODE_TAPS loop (A/B runs)
-    if (halo < 0) halo = getenv("HMV_NO_HALO") ? 0 : 1;
+    if (halo < 0) halo = HMV_DEV_ENV("HMV_NO_HALO") ? 0 : 1;
     const bool use_halo = halo && p.in_f16 && (tile == TILE_256x256 || tile == TILE_256x128) && !generic && !dense && !p.x3_plane && !p.cwrap && !p.rd_cout &&
                           p.ksl <= 1 && !p.in2 && !p.res && !p.up && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad_h == 1 && p.pad_w == 1 &&
                           p.Ho == p.H && p.Wo == p.W && p.H % 16 == 0 && p.W % 16 == 0 && p.Cin % 64 == 0 && p.lda == p.Cin &&
@@ -1449,7 +1449,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     // last N-tile with >= 32 all-padding columns: the block-skipping instantiations (fp32, the three big tiles)
     const int mode = dense ? MODE_DENSE : (one ? MODE_1X1 : MODE_TAPS);
     static int no_skip = -1;   // development knob: HMV_NO_SKIPN=1 disables the block-skipping instantiations (A/B runs)
-    if (no_skip < 0) { const char *e = getenv("HMV_NO_SKIPN"); no_skip = e ? atoi(e) : 0; }
+    if (no_skip < 0) { const char *e = HMV_DEV_ENV("HMV_NO_SKIPN"); no_skip = e ? atoi(e) : 0; }
     const bool partn = !no_skip && !p.in_f16 && !generic && conv_partial_n(tile, p.Cout) && !(dense && tile == TILE_256x256);
     if (name) *name = p.in_f16 ? conv_tile_name_f16(tile, mode) : tile_name("f32", tile, mode, partn);
     if (partn) {
@@ -1470,7 +1470,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         if (p.in_f16) {
             // 129 .. 192 output channels (HRNet-w40's 160-channel branch): ONE 192-wide N-tile instead of two 128-wide ones whose
             // second is three quarters padding (6 instead of 8 MFMA column blocks per pixel block)
-            static const bool no192 = getenv("HMV_NO_N192") != nullptr;   // development knob (A/B runs)
+            static const bool no192 = HMV_DEV_ENV("HMV_NO_N192") != nullptr;   // development knob (A/B runs)
             if (tile == TILE_256x128 && p.Cout > 128 && p.Cout <= 192 && !generic && !no192) {
                 // (128 x 192 tiles, two 4-wave workgroups per CU, measured 28 % slower on the one-round launches of HRNet-w40: 3.82 vs 2.98 ms)
                 if (name) *name = "conv_igemm_f16<256x192,dense>";
@@ -1514,7 +1514,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         case TILE_128x64: {
             // 64-channel 3x3 convs over many pixels (layer1 conv2): ONE 8-wave workgroup per 256 pixels instead of two 4-wave ones
             // per 128 -- 664 -> 640 us (round 3; HMV_NO_T256x64=1 for A/B runs).  Same accumulation order: same bits.
-            static const bool no25664 = getenv("HMV_NO_T256x64") != nullptr;
+            static const bool no25664 = HMV_DEV_ENV("HMV_NO_T256x64") != nullptr;
             if (!no25664 && !generic && !one && p.Cout == 64 && p.M >= 524288) {
                 if (name) *name = "conv_igemm_f32<256x64,taps>";
                 return launch_plain<float, 256, 64, 4, 2, 32>(p, false, s);

@@ -215,7 +215,7 @@ void conv_rds_set_mode(int mode) { g_rds_mode = mode; }
 
 bool conv_rds_supported(const ConvParams &p) {
     static int off = -1;   // development knob: HMV_NO_RDS=1 keeps these layers on conv_igemm's row-decomposed tiles (A/B runs)
-    if (off < 0) off = getenv("HMV_NO_RDS") ? 1 : 0;
+    if (off < 0) off = HMV_DEV_ENV("HMV_NO_RDS") ? 1 : 0;
     if (g_rds_mode == 0 || (g_rds_mode < 0 && off)) return false;
     if (p.in_f16 || p.out_f16 || p.res_f16 || (p.rd_cout != 40 && p.rd_cout != 80)) return false;
     if (p.R != 3 || p.S != 1 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 0 || p.Cout != 3 * p.rd_cout || p.Cin != p.rd_cout) return false;

@@ -645,19 +645,19 @@ static int stream32_shape(const ConvParams &p) {   // 0 none; 1 residual-bearing
 // 256 x 128 workgroups per CU (1 172 vs 1 143 us); as two four-wave workgroups per CU on 64 x 128 tiles (HALF) the epilogues overlap the
 // other workgroup's MFMAs again and it is 1.8 % faster (1 125 us).
 static bool stream32_rule(const ConvParams &p) {
-    static const bool no256 = getenv("HMV_NO_STREAM32_K256") != nullptr;   // development knob (A/B runs)
+    static const bool no256 = HMV_DEV_ENV("HMV_NO_STREAM32_K256") != nullptr;   // development knob (A/B runs)
     return p.res ? (p.Kpad <= 128 || (!no256 && p.Cout % 128 == 0 && 64 % (p.Cout / 128) == 0)) : true;
 }
 
 bool conv_stream_supported(const ConvParams &p) {
     static int off = -1;   // development knob: HMV_NO_STREAM=1 keeps every conv on conv_igemm (A/B runs)
-    if (off < 0) off = getenv("HMV_NO_STREAM") ? 1 : 0;
+    if (off < 0) off = HMV_DEV_ENV("HMV_NO_STREAM") ? 1 : 0;
     static int min_env = -1;   // tiles per workgroup below which the per-tile workgroups of conv_igemm fill the chip better
-    if (min_env < 0) { const char *e = getenv("HMV_STREAM_MIN_TILES"); min_env = e ? atoi(e) : 4; }
+    if (min_env < 0) { const char *e = HMV_DEV_ENV("HMV_STREAM_MIN_TILES"); min_env = e ? atoi(e) : 4; }
     if (g_stream_mode == 0 || (g_stream_mode < 0 && off)) return false;
     const int min_tiles = g_stream_mode > 0 ? 0 : min_env;
     if (stream32_shape(p)) {
-        static const bool off32 = getenv("HMV_NO_STREAM32") != nullptr;   // development knob (A/B runs)
+        static const bool off32 = HMV_DEV_ENV("HMV_NO_STREAM32") != nullptr;   // development knob (A/B runs)
         if (off32 && g_stream_mode <= 0) return false;
         if (p.R != 1 || p.S != 1 || p.stride != 1 || p.pad_h || p.pad_w || p.up || p.ksl > 1 || p.phases > 1) return false;
         if (p.cwrap || p.x3_plane || p.res_split || p.out_split || p.acc_shift || p.rd_cout || p.scatter || p.rg_out || p.fill) return false;
@@ -684,7 +684,7 @@ bool conv_stream_supported(const ConvParams &p) {
 // chain (ConvParams::nx_*): the fp16 launches whose workgroup owns all output channels of its pixel tile -- Bottleneck conv3 of layer1
 // (64 -> 256 + residual; conv3 + downsample of layer1.0 as two sources) -- followed by a 1x1 conv 256 -> 64 / 128 + ReLU
 bool conv_stream_chain_ok(const ConvParams &q, int nx_cout) {
-    static const bool off = getenv("HMV_NO_CHAIN") != nullptr;   // development knob (A/B runs)
+    static const bool off = HMV_DEV_ENV("HMV_NO_CHAIN") != nullptr;   // development knob (A/B runs)
     if (off || (nx_cout != 64 && nx_cout != 128)) return false;
     ConvParams p = q;
     p.nx_wgt = nullptr;
@@ -734,7 +734,7 @@ hipError_t launch_conv_stream(const ConvParams &p, hipStream_t s, const char **n
     // gains 3-4 % at K = 256 (four piece steps) and loses 4 % at K = 128; non-temporal loads lose 15-25 % everywhere (the next
     // launch finds less of its input in the Infinity Cache).  Default: spread at K = 256 only.
     static int variant = -1;
-    if (variant < 0) { const char *e = getenv("HMV_STREAM_VARIANT"); variant = e ? atoi(e) : -1; if (variant < 0) variant = 100; }
+    if (variant < 0) { const char *e = HMV_DEV_ENV("HMV_STREAM_VARIANT"); variant = e ? atoi(e) : -1; if (variant < 0) variant = 100; }
 #define HMV_STREAM_VARIANTS(...)                                                                            \
     switch (variant) {                                                                                      \
         case 1: return launch_stream_one<__VA_ARGS__, true, true, 0>(p, s);                                 \

@@ -365,7 +365,7 @@ struct Loader {
         const int plane = cin_pad ? cin_pad : Cin;            // physical channels (per plane when split)
         const bool sp = split && f16;
         // fused split reduction: a k-step = 32 channels as [32 hi | 32 lo] halfs, K order (32-channel chunk, r, s, plane, c % 32)
-        const bool x3n = sp && plane % 8 == 0 && !getenv("HMV_NO_X3N");
+        const bool x3n = sp && plane % 8 == 0 && !HMV_DEV_ENV("HMV_NO_X3N");
         const int cp = sp ? (x3n ? 2 * plane : 3 * plane) : plane;   // the channel count the kernel's K order walks
         const float *wd = wsrc ? wsrc : w->data.data();
         const bool chunked = cp % (f16 ? 64 : 32) == 0 && (!sp || (x3n && plane % 32 == 0) || (!x3n && plane % 64 == 0));
@@ -483,7 +483,15 @@ int backbone_level_channels(const hmv_config &c, int level /*0 = layer1*/) {
 // ====================================================================== C ABI
 extern "C" {
 
-const char *hmv_version(void) { return "handmv-mi355x 0.1 (gfx950, fp32 MFMA)"; }
+const char *hmv_version(void) {
+#ifdef HMV_DEV_KNOBS
+    return "handmv-mi355x 0.4-dev (gfx950; arithmetic modes: f32 = native fp32 MFMA, f16 = fp16 storage + fp16 MFMA with fp32 accumulation, "
+           "f32x3 = (hi, lo) fp16 pairs on the fp16 MFMA, fp32-equivalent; development knobs compiled in)";
+#else
+    return "handmv-mi355x 0.4 (gfx950; arithmetic modes: f32 = native fp32 MFMA, f16 = fp16 storage + fp16 MFMA with fp32 accumulation, "
+           "f32x3 = (hi, lo) fp16 pairs on the fp16 MFMA, fp32-equivalent)";
+#endif
+}
 
 // The tile conv_igemm's launcher rule gives a conv / GEMM of M output pixels, Cout channels and reduction length K ("256x256", "128x32",
 // "256x128,k16,w8" ...): host logic only, no GPU call -- the CPU tests pin the rules that were measured on the hardware.
@@ -531,8 +539,8 @@ int hmv_create(const hmv_config *cfg, hmv_handle *out) {
     if (cfg->device < 0 || cfg->device >= ndev) return bad("device ordinal out of range");
     hmv_engine *h = new hmv_engine();
     if (const char *g = getenv("HMV_GRAPHS")) h->graphs = atoi(g) != 0;
-    h->ff_fuse = getenv("HMV_NO_FFFUSE") == nullptr;
-    h->cheb_fuse = getenv("HMV_NO_CHEBFUSE") == nullptr;
+    h->ff_fuse = HMV_DEV_ENV("HMV_NO_FFFUSE") == nullptr;
+    h->cheb_fuse = HMV_DEV_ENV("HMV_NO_CHEBFUSE") == nullptr;
     h->cfg = *cfg;
     h->paper = paper;
     h->hrnet = hrnet;
@@ -584,13 +592,13 @@ int hmv_finalize_weights(hmv_handle h) {
         bool rdb[4] = {false, false, false, false};
         for (int b = 0; b < 2; ++b)
             rdb[b] = 3 * hr.ch[b] <= 256 && hr.ch[b] % 32 != 0 && hr.ch[b] % 4 == 0 && 128 % (c.width / (4 << b)) == 0 && !L.split &&
-                     !getenv("HMV_NO_ROWSUM");
+                     !HMV_DEV_ENV("HMV_NO_ROWSUM");
         // fp16 path, 40-channel branch on frames whose H/4 x W/4 map tiles into 16 x 16 blocks: plain (r, s, c) packing instead, so
         // that the weight-stationary halo-streaming kernel (conv_hs.hip: 1.9 -> ~4 TB/s on these layers) takes the large batches
         // and conv_igemm's dense mode -- same K order, same bits -- the small ones.  Decided by the configuration, never by the batch.
-        if (h16 && !L.split && hr.ch[0] == 40 && c.height % 64 == 0 && c.width % 64 == 0 && !getenv("HMV_NO_HS")) rdb[0] = false;
+        if (h16 && !L.split && hr.ch[0] == 40 && c.height % 64 == 0 && c.width % 64 == 0 && !HMV_DEV_ENV("HMV_NO_HS")) rdb[0] = false;
         // ... and the 80-channel branch (H/8 x W/8 maps in 8 x 16 blocks; conv_hs.hip's three-wave variant)
-        if (h16 && !L.split && hr.ch[1] == 80 && c.height % 64 == 0 && c.width % 128 == 0 && !getenv("HMV_NO_HS") && !getenv("HMV_NO_HS80")) rdb[1] = false;
+        if (h16 && !L.split && hr.ch[1] == 80 && c.height % 64 == 0 && c.width % 128 == 0 && !HMV_DEV_ENV("HMV_NO_HS") && !HMV_DEV_ENV("HMV_NO_HS80")) rdb[1] = false;
         const bool rd0 = rdb[0];
         L.conv(hr.conv1, "stem.conv1", "backbone.conv1.weight", "", "backbone.bn1", 64, 3, 3, 3, /*cin_pad=*/h16 ? 8 : 4, h16);
         L.conv(hr.conv2, "stem.conv2", "backbone.conv2.weight", "", "backbone.bn2", 64, 64, 3, 3, 0, h16);
@@ -715,7 +723,7 @@ int hmv_finalize_weights(hmv_handle h) {
             }
             b.has_ds = (b.stride != 1 || inpl != outc);
             if (b.has_ds) L.conv(b.ds, lab + ".downsample", p + ".downsample.0.weight", "", p + ".downsample.1", outc, inpl, 1, 1, 0, h16);
-            static const bool no_fuse = getenv("HMV_NO_DSFUSE") != nullptr;   // development knob (A/B runs)
+            static const bool no_fuse = HMV_DEV_ENV("HMV_NO_DSFUSE") != nullptr;   // development knob (A/B runs)
             if (b.has_ds && h->paper && !L.split && !no_fuse) {
                 const int CHK = h16 ? 64 : 32;
                 const HostTensor *w3 = L.get(p + ".conv3.weight", {outc, planes, 1, 1}), *wd = L.get(p + ".downsample.0.weight", {outc, inpl, 1, 1});
@@ -776,7 +784,7 @@ int hmv_finalize_weights(hmv_handle h) {
             // the four phases' weight blocks back to back: one launch runs all of them (conv_igemm.hip, p.phases).  Not in the
             // split mode, whose per-layer power-of-two weight scale differs between the phases.
             h->deconv_all = Layer();
-            if (!(L.split && h16) && !getenv("HMV_NO_PHASEMERGE") && L.rc == HMV_OK) {
+            if (!(L.split && h16) && !HMV_DEV_ENV("HMV_NO_PHASEMERGE") && L.rc == HMV_OK) {
                 const Layer &d0 = h->deconv[0];
                 const size_t elems = (size_t)d0.Cout_pad * d0.Kpad, bytes = elems * (h16 ? 2 : 4);
                 void *all = nullptr;
@@ -824,7 +832,7 @@ int hmv_finalize_weights(hmv_handle h) {
     }
     // fp16 / f32x3 modes: the q/k/v projections (the fusion stage's largest GEMMs) run on the fused split fp16 kernels --
     // fp32-equivalent results at a third of the fp32 MFMA time.  Chosen by dtype alone, never by the batch.
-    const bool x3lin = h16 && !getenv("HMV_NO_X3LIN");
+    const bool x3lin = h16 && !HMV_DEV_ENV("HMV_NO_X3LIN");
     if (h->lq) {
         // CrossAttentionFusionLearnableQuery: fusion.py:33-49; MultiHeadAttentionLearnableQuery: layers.py:240-301
         for (int l = 0; l < 5; ++l) {
@@ -958,16 +966,16 @@ int hmv_finalize_weights(hmv_handle h) {
 int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t R, int32_t S,
                    int32_t stride, int32_t pad, int32_t with_residual, int32_t tile, int32_t iters, float *avg_ms) {
     if (hipSetDevice(device) != hipSuccess) return HMV_ERR_HIP;
-    const char *edt = getenv("HMV_BENCH_DTYPE");
+    const char *edt = HMV_DEV_ENV("HMV_BENCH_DTYPE");
     const bool f16 = edt && std::string(edt) == "f16";
     const size_t eb = f16 ? 2 : 4;
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     const int K = R * S * Cin, Kpad = round_up(K, f16 ? 64 : 32), Cp = round_up(Cout, 256);
-    const char *ea = getenv("HMV_BENCH_APAD"), *ew = getenv("HMV_BENCH_WPAD");
+    const char *ea = HMV_DEV_ENV("HMV_BENCH_APAD"), *ew = HMV_DEV_ENV("HMV_BENCH_WPAD");
     const int lda = Cin + (ea ? atoi(ea) : 0), ldw = Kpad + (ew ? atoi(ew) : 0);
     const size_t nin = (size_t)N * H * W * lda, nout = (size_t)N * Ho * Wo * Cout, nw = (size_t)Cp * ldw;
     float *din = nullptr, *dout = nullptr, *dw = nullptr, *db = nullptr, *dres = nullptr;
-    const char *esk = getenv("HMV_BENCH_SKEW");   // bytes by which the output buffer is displaced inside its allocation
+    const char *esk = HMV_DEV_ENV("HMV_BENCH_SKEW");   // bytes by which the output buffer is displaced inside its allocation
     const size_t skew = esk ? (size_t)atol(esk) : 0;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&din), nin * eb);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dout), nout * eb + skew);
@@ -1001,10 +1009,10 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
         p.R = R; p.S = S; p.stride = stride; p.pad_h = pad; p.pad_w = pad; p.K = K; p.Kpad = Kpad;
         p.M = N * Ho * Wo; p.ldc = Cout; p.ldr = Cout; p.act = ACT_RELU; p.osy = p.osx = 1;
         p.lda = lda; p.ldw = ldw;
-        p.tall = getenv("HMV_BENCH_TALL") != nullptr;   // the tall-tile 3x3 kernel (conv_ht.hip); random weights have no order
+        p.tall = HMV_DEV_ENV("HMV_BENCH_TALL") != nullptr;   // the tall-tile 3x3 kernel (conv_ht.hip); random weights have no order
         unsigned long long *ddbg = nullptr;
         const int nblk_dbg = ((p.M + 63) / 64) * ((Cout + 31) / 32);
-        if (getenv("HMV_BENCH_CLOCK")) {
+        if (HMV_DEV_ENV("HMV_BENCH_CLOCK")) {
             (void)hipMalloc(reinterpret_cast<void **>(&ddbg), (size_t)nblk_dbg * 64);
             (void)hipMemset(ddbg, 0, (size_t)nblk_dbg * 64);
             p.dbg = ddbg;
@@ -1023,10 +1031,10 @@ int hmv_bench_conv(int32_t device, int32_t N, int32_t H, int32_t W, int32_t Cin,
         if (ddbg) {
             std::vector<unsigned long long> hd((size_t)nblk_dbg * 8);
             (void)hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost);
-            if (const char *dump = getenv("HMV_BENCH_DUMP")) {
+            if (const char *dump = HMV_DEV_ENV("HMV_BENCH_DUMP")) {
                 if (FILE *f = fopen(dump, "wb")) { fwrite(hd.data(), 8, hd.size(), f); fclose(f); }
             }
-            if (getenv("HMV_BENCH_PHASES"))   // conv_hs.hip: {wait, main loop, epilogue} cycles of workgroup 0's first wave, blocks, total
+            if (HMV_DEV_ENV("HMV_BENCH_PHASES"))   // conv_hs.hip: {wait, main loop, epilogue} cycles of workgroup 0's first wave, blocks, total
                 fprintf(stderr, "[phases] wait %llu main %llu epilogue %llu blocks %llu total %llu\n", hd[0], hd[1], hd[2], hd[3], hd[4]);
             std::vector<double> clk, cyc;
             for (int i = 0; i < nblk_dbg; ++i)
@@ -1187,7 +1195,7 @@ struct Runner {
     }
 
     static int splitk_slices(const Layer &L, int rows) {
-        static const bool no_splitk = getenv("HMV_NO_SPLITK") != nullptr;   // development knob (A/B runs)
+        static const bool no_splitk = HMV_DEV_ENV("HMV_NO_SPLITK") != nullptr;   // development knob (A/B runs)
         return (!no_splitk && !L.f16 && L.R == 1 && L.S == 1 && !L.plane && L.Kpad >= 1024 && L.Kpad % 128 == 0 &&
                 L.Cout <= 4096 /* zero_bias */ && rows > 0) ? 4 : 1;
     }
@@ -1248,8 +1256,9 @@ struct Runner {
             p.n1g = n1g; p.n1b = n1b; p.fg = fg; p.fb = fb; p.n2g = n2g; p.n2b = n2b;
             p.w1 = ff1.w; p.b1 = ff1.bias; p.ldw1 = ff1.Kpad; p.w2 = ff2.w; p.b2 = ff2.bias; p.ldw2 = ff2.Kpad;
             p.out = y; p.ldo = ldt; p.hid = ff1.Cout;
-            static unsigned long long *ffdbg = nullptr;   // HMV_FF_DBG=1: phase stamps of the last launch, printed by the next one
-            if (getenv("HMV_FF_DBG")) {
+#ifdef HMV_DEV_KNOBS
+            static unsigned long long *ffdbg = nullptr;   // HMV_FF_DBG=1: phase stamps of the last launch, printed by the next one (never under graph capture)
+            if (HMV_DEV_ENV("HMV_FF_DBG")) {
                 if (!ffdbg) (void)hipMalloc(reinterpret_cast<void **>(&ffdbg), 4096 * 64);
                 else {
                     unsigned long long hst[8 * 4];
@@ -1262,6 +1271,7 @@ struct Runner {
                 }
                 p.dbg = ffdbg;
             }
+#endif
             check(launch_ff_block(p, s), "ff_block");
             ++h->launches;
         }
@@ -1775,7 +1785,8 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
 
     // ---- decoder (nets.py:133-139 / 150-154)
     const int jr = B * NJ;
-    if (c.decoder == HMV_DECODER_GCN && h->cheb_fuse && ldt % 16 == 0 && h->gcn[0].Kpad == ldt) {
+    if (c.decoder == HMV_DECODER_GCN && h->cheb_fuse && h->gcn[0].Kpad == ldt &&
+        cheb_fusable(ldt, ldt, h->gcn[0].Kpad, 256, h->gcn[1].Kpad, 64, h->gcn[2].Kpad, 3)) {
         // the three ChebConv layers in two launches (fusion_kernels.hip): layer 1 per (sample, 16 channels), layers 2 + 3 per sample
         float *scr = R.alloc((size_t)jr * 256);
         if (!dry && R.rc == HMV_OK) {

@@ -465,14 +465,22 @@ __global__ __launch_bounds__(512) void cheb_tail_kernel(const float *__restrict_
     }
 }
 
+// Host predicate: the shapes the two fused ChebConv launches take (the engine asks it BEFORE choosing the fused branch, so that a
+// shape outside it -- a wider token matrix, another decoder width -- takes the launch-per-op branch instead of failing the forward).
+bool cheb_fusable(int K, int ldx, int ldw1, int c1, int ldw2, int c2, int ldw3, int c3) {
+    if (K > 16 * FF_NV1 || c1 > 256 || c2 > 64 || 2 * (3 * c2 / 16) > 24 || K % 16 || ldx < K || ldw1 < K || c1 % 16 || (3 * c2) % 16 || c2 % 16 || 3 * c3 > 16 ||
+        ldw2 < c1 || ldw3 < c2 || (ldx & 3) || (ldw1 & 3) || (ldw2 & 3) || (ldw3 & 3))
+        return false;
+    const size_t lds1 = ((size_t)32 * (K + CH_LDX_PAD) + 3 * 32 * 16 + 3 * 21 * 21) * sizeof(float);
+    const size_t lds2 = ((size_t)32 * (c1 + 4) + 32 * (3 * c2 + 4) + 32 * (c2 + 4) + 3 * 21 * 21 + 32 * 16) * sizeof(float);
+    return lds1 <= 160 * 1024 && lds2 <= 160 * 1024;
+}
+
 hipError_t launch_cheb_fused(const ChebFusedParams &p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
-    if (p.K > 16 * FF_NV1 || p.c1 > 256 || p.c2 > 64 || 2 * (3 * p.c2 / 16) > 24 || p.K % 16 || p.ldx < p.K || p.ldw1 < p.K || p.c1 % 16 || (3 * p.c2) % 16 || p.c2 % 16 || 3 * p.c3 > 16 || p.ldw2 < p.c1 || p.ldw3 < p.c2 ||
-        (p.ldx & 3) || (p.ldw1 & 3) || (p.ldw2 & 3) || (p.ldw3 & 3) || !p.scratch)
-        return hipErrorInvalidValue;
+    if (!cheb_fusable(p.K, p.ldx, p.ldw1, p.c1, p.ldw2, p.c2, p.ldw3, p.c3) || !p.scratch) return hipErrorInvalidValue;
     const size_t lds1 = ((size_t)32 * (p.K + CH_LDX_PAD) + 3 * 32 * 16 + 3 * 21 * 21) * sizeof(float);
     const size_t lds2 = ((size_t)32 * (p.c1 + 4) + 32 * (3 * p.c2 + 4) + 32 * (p.c2 + 4) + 3 * 21 * 21 + 32 * 16) * sizeof(float);
-    if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return hipErrorInvalidValue;
     static bool configured[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;

@@ -2,6 +2,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+// Development knobs (A/B switches, probes: DESIGN.md section 9) exist only in a -DHMV_DEV_KNOBS build
+// (`python -m handmvnet_amd.build --variant dev HMV_DEV_KNOBS` -> build/libhandmv_dev.so, loaded with HMV_LIB=...).  The product
+// library reads ONE environment variable, HMV_GRAPHS; tests/test_abi_cpu.py holds its strings to that.
+#ifdef HMV_DEV_KNOBS
+#define HMV_DEV_ENV(name) getenv(name)
+#else
+#define HMV_DEV_ENV(name) (static_cast<const char *>(nullptr))
+#endif
 
 namespace hmv {
 
@@ -210,6 +220,7 @@ struct ChebFusedParams {
     float *out; int ldo;
 };
 hipError_t launch_cheb_fused(const ChebFusedParams &p, hipStream_t s);
+bool cheb_fusable(int K, int ldx, int ldw1, int c1, int ldw2, int c2, int ldw3, int c3);   // the shapes launch_cheb_fused takes
 
 // NHWC -> NCHW copy (stage capture)
 hipError_t launch_nhwc_to_nchw(const float *in, float *out, int N, int H, int W, int C, hipStream_t s, int ld = 0);

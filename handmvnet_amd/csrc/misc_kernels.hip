@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void soft_argmax_frame_kernel(const float *__r
 }
 hipError_t launch_soft_argmax(const float *hm, int ld, int N, int h, int w, float *coords, float *crop_img,
                               float image_size, float heatmap_size, float *hm_nchw, hipStream_t s) {
-    static const bool no_frame = getenv("HMV_SOFTARGMAX_WAVE") != nullptr;   // development knob (A/B runs)
+    static const bool no_frame = HMV_DEV_ENV("HMV_SOFTARGMAX_WAVE") != nullptr;   // development knob (A/B runs)
     if (!no_frame && ld == 32 && h * w <= 1024) {
         hipLaunchKernelGGL(soft_argmax_frame_kernel, dim3(N), dim3(256), 0, s, hm, h, w, coords, crop_img, image_size, heatmap_size, hm_nchw);
         return hipGetLastError();
@@ -954,7 +954,7 @@ hipError_t launch_attention_d256(const float *q, int q_ld, int q_bstride, const 
     if (T <= 0 || Tq <= 0) return hipErrorInvalidValue;
     // QK^T and PV on the fp32 matrix cores like the 128-wide heads (the same kernel template, D = 256); HMV_LQ_SCALAR_ATT=1
     // keeps the wave-per-query-row form below (A/B runs, read per launch)
-    if (!getenv("HMV_LQ_SCALAR_ATT")) return launch_attention_any<256>(q, q_ld, q_bstride, k, v, kv_ld, B, T, Tq, T, out, s);
+    if (!HMV_DEV_ENV("HMV_LQ_SCALAR_ATT")) return launch_attention_any<256>(q, q_ld, q_bstride, k, v, kv_ld, B, T, Tq, T, out, s);
     hipLaunchKernelGGL(attention_d256_kernel, dim3(B * 8), dim3(256), 0, s, q, q_ld, q_bstride, k, v, kv_ld, T, Tq, out);
     return hipGetLastError();
 }

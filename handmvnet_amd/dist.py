@@ -45,7 +45,10 @@ class ResultGatherer:
         allocates nothing); gather_outputs() hands out copies."""
         cam, img = local["joints_cam"], local["joints_crop_img"]
         n = cam.shape[0]
-        assert n <= self.n_max and img.shape[0] == n, "local shard larger than the gatherer was built for"
+        # raised, never asserted: under `python -O` a rank with a wrong shard would otherwise enter an all-gather of another size
+        # and the job would hang instead of failing
+        if n > self.n_max or img.shape[0] != n:
+            raise ValueError(f"local shard of {n} samples does not fit the gatherer (built for {self.n_max})")
         if n:
             self.send[:n, :63].copy_(cam.reshape(n, 63))
             self.send[:n, 63:].copy_(img.reshape(n, self.row - 63))
@@ -53,11 +56,13 @@ class ResultGatherer:
         self.collectives += 1
         blocks = self.recv.view(self.world, self.n_max, self.row)
         if total is None or total == self.n_max * self.world:
-            full = blocks.reshape(self.world * self.n_max, self.row) if n == self.n_max else None
-            assert full is not None, "equal shards expected (pass total= for ragged ones)"
+            if n != self.n_max:
+                raise ValueError("equal shards expected (pass total= for ragged ones)")
+            full = blocks.reshape(self.world * self.n_max, self.row)
         else:
             spans = [shard_range(total, r, self.world) for r in range(self.world)]
-            assert spans[self.rank][1] - spans[self.rank][0] == n, "local shard does not match shard_range"
+            if spans[self.rank][1] - spans[self.rank][0] != n:
+                raise ValueError(f"local shard of {n} samples does not match shard_range{spans[self.rank]} of total={total}")
             full = torch.cat([blocks[r, :b_ - a_] for r, (a_, b_) in enumerate(spans)], dim=0)
         rows = full.shape[0]
         return {"joints_cam": full[:, :63].reshape(rows, 21, 3), "joints_crop_img": full[:, 63:].reshape(rows, self.views, 21, 2)}
@@ -66,12 +71,25 @@ class ResultGatherer:
 _GATHERERS: Dict[tuple, ResultGatherer] = {}
 
 
+def _default_group():
+    """The live default ProcessGroup object (group=None means "whatever the default is NOW": after destroy_process_group +
+    init_process_group that is a NEW object, and a gatherer cached for the old one holds a dead handle)."""
+    try:
+        return dist.distributed_c10d._get_default_group()
+    except Exception:   # noqa: BLE001 -- private API; fall back to "never reuse"
+        return None
+
+
 def gatherer_for(n_max: int, views: int, device, group=None) -> ResultGatherer:
-    """The cached ResultGatherer of this (group, shard size, views, device): buffers are allocated on first use only."""
-    key = (id(group), int(n_max), int(views), str(device))
-    g = _GATHERERS.get(key)
-    if g is None or g.world != dist.get_world_size(group):
-        g = _GATHERERS[key] = ResultGatherer(n_max, views, device, group)
+    """The cached ResultGatherer of this (group, shard size, views, device): buffers are allocated on first use only.  A cache hit
+    must be for the SAME process-group object (held strongly by the entry, so its id cannot be recycled while the entry lives)."""
+    pg = group if group is not None else _default_group()
+    key = (id(pg), int(n_max), int(views), str(device))
+    hit = _GATHERERS.get(key)
+    if hit is not None and pg is not None and hit[0] is pg and hit[1].world == dist.get_world_size(group):
+        return hit[1]
+    g = ResultGatherer(n_max, views, device, group)
+    _GATHERERS[key] = (pg, g)
     return g
 
 
@@ -83,7 +101,12 @@ def reset_gatherers() -> None:
 def gather_outputs(local: Dict[str, torch.Tensor], total: Optional[int] = None, group=None,
                    keys=KEYS) -> Dict[str, torch.Tensor]:
     """All-gathers per-sample results along dim 0 in rank order with ONE collective.  `total` (global sample
-    count) is needed only for ragged shards."""
+    count) is needed only for ragged shards.  `keys` selects among the two packed results (joints_cam, joints_crop_img); heat maps
+    stay local by design (22 MB per rank), so any other key is refused with a clear error rather than a KeyError mid-gather."""
+    keys = tuple(keys)
+    bad = [k for k in keys if k not in KEYS]
+    if bad:
+        raise ValueError(f"gather_outputs gathers {KEYS} only (one packed collective); cannot gather {bad}")
     if not (dist.is_available() and dist.is_initialized()):
         return {k: local[k] for k in keys}
     world = dist.get_world_size(group)

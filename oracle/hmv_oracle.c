@@ -803,6 +803,76 @@ typedef struct {
     int fusion;                   /* 0 = cross_attn (fusion.py:7-30), 1 = cross_attn_learnable_query (fusion.py:33-49) */
 } hmvo_config;
 
+/* The part of HandMvNet.forward behind the token matrix (handmvnet.py:225-229): joints_late_fusion, then joints_decoder.
+ * tok [B][V*21][d] (before the positional encoding) is CONSUMED (freed).  Shared by hmvo_forward and hmvo_fuse_tokens. */
+static void fuse_and_decode(const hmvo_config *cfg, int B, int d, float *tok, float *fused_out, float *joints_cam) {
+    int V = cfg->num_views;
+    /* ---- CrossAttentionFusion.forward: fusion.py:26-30 ; PositionalEncoding: layers.py:134-158 */
+    int Tn = V * NJ;
+    if (cfg->fusion == 1) {
+        /* CrossAttentionFusionLearnableQuery.forward (fusion.py:47-49): 5 blocks, the middle one with the probe queries;
+         * every block adds its own positional embedding, so nothing is added here whatever pos_enc says */
+        float *f = tok;
+        int Tcur = Tn;
+        for (int l = 0; l < 5; ++l) {
+            float *nf = mha_lq_block(f, B, Tcur, d, l, l == 2, &Tcur);
+            free(f);
+            f = nf;
+        }
+        tok = f;
+    } else if (cfg->pos_mask & 4) {
+        for (int p = 0; p < Tn; ++p)
+            for (int c = 0; c < d; ++c) {
+                int k2 = c & ~1;
+                float div = expf((float)k2 * (float)(-log(10000.0) / (double)d));
+                float ang = (float)p * div;
+                float pe = (c & 1) ? cosf(ang) : sinf(ang);
+                for (int b = 0; b < B; ++b) tok[((size_t)b * Tn + p) * d + c] += pe;
+            }
+    }
+    int half = (cfg->fusion_layers - 1) / 2, Tcur = Tn;
+    float *f = tok;
+    for (int l = 0; l < (cfg->fusion == 1 ? 0 : cfg->fusion_layers); ++l) {
+        float *nf = mha_block(f, B, Tcur, d, l, l == half ? NJ : 0, &Tcur);
+        free(f);
+        f = nf;
+    }
+    if (fused_out) memcpy(fused_out, f, sizeof(float) * (size_t)B * NJ * d);
+    /* ---- decoder: nets.py:133-139 / 150-154 */
+    if (cfg->use_gcn) {
+        float *g1 = falloc((size_t)B * NJ * 256), *g2 = falloc((size_t)B * NJ * 64);
+        cheb_conv(f, B, d, 256, "joints_decoder.joints_gcn1", 1, g1);
+        cheb_conv(g1, B, 256, 64, "joints_decoder.joints_gcn2", 1, g2);
+        cheb_conv(g2, B, 64, 3, "joints_decoder.joints_gcn3", 0, joints_cam);
+        free(g1);
+        free(g2);
+    } else {
+        float *g1 = falloc((size_t)B * NJ * 64);
+        linear(f, B * NJ, d, T("joints_decoder.joints_fc1.weight")->data, T("joints_decoder.joints_fc1.bias")->data, 64, g1);
+        for (size_t i = 0; i < (size_t)B * NJ * 64; ++i) g1[i] = g1[i] < 0.f ? 0.01f * g1[i] : g1[i];
+        linear(g1, B * NJ, 64, T("joints_decoder.joints_fc2.weight")->data, T("joints_decoder.joints_fc2.bias")->data, 3,
+               joints_cam);
+        free(g1);
+    }
+    free(f);
+}
+
+/* Test entry: the fusion + decoder tail alone, on a token matrix supplied by the caller (e.g. the one an implementation
+ * under test captured), so that an implementation's tail can be checked apart from the conditioning of what precedes it.
+ * tokens [B][V*21][d] is not modified. */
+int hmvo_fuse_tokens(const hmvo_config *cfg, int B, const float *tokens, float *fused_out, float *joints_cam) {
+    g_missing = 0;
+    g_err[0] = 0;
+    int fdim = 0;
+    for (int i = 0; i < cfg->n_levels; ++i) fdim += cfg->channels[i] / 2;
+    int d = fdim + ((cfg->pos_mask & 1) ? 2 : 0) + ((cfg->pos_mask & 2) ? 10 : 0);
+    size_t n = (size_t)B * cfg->num_views * NJ * d;
+    float *tok = falloc(n);
+    memcpy(tok, tokens, sizeof(float) * n);
+    fuse_and_decode(cfg, B, d, tok, fused_out, joints_cam);
+    return g_missing ? 3 : 0;
+}
+
 /* HandMvNet.forward: models/handmvnet.py:158-266.
  * x [B][V][3][H][W]; bbox [B][V][4]; intr [B][V][4].
  * Optional stage dumps (may be NULL): feat0 = feats[0] NCHW, coords_hm [B*V][21][2] (heat-map units),
@@ -933,54 +1003,7 @@ int hmvo_forward(const hmvo_config *cfg, int B, int H, int W, const float *x, co
     }
     for (int l = 0; l < 4; ++l) free(lv[l]);
     if (tokens_out) memcpy(tokens_out, tok, sizeof(float) * (size_t)N * NJ * d);
-    /* ---- CrossAttentionFusion.forward: fusion.py:26-30 ; PositionalEncoding: layers.py:134-158 */
-    int Tn = V * NJ;
-    if (cfg->fusion == 1) {
-        /* CrossAttentionFusionLearnableQuery.forward (fusion.py:47-49): 5 blocks, the middle one with the probe queries;
-         * every block adds its own positional embedding, so nothing is added here whatever pos_enc says */
-        float *f = tok;
-        int Tcur = Tn;
-        for (int l = 0; l < 5; ++l) {
-            float *nf = mha_lq_block(f, B, Tcur, d, l, l == 2, &Tcur);
-            free(f);
-            f = nf;
-        }
-        tok = f;
-    } else if (cfg->pos_mask & 4) {
-        for (int p = 0; p < Tn; ++p)
-            for (int c = 0; c < d; ++c) {
-                int k2 = c & ~1;
-                float div = expf((float)k2 * (float)(-log(10000.0) / (double)d));
-                float ang = (float)p * div;
-                float pe = (c & 1) ? cosf(ang) : sinf(ang);
-                for (int b = 0; b < B; ++b) tok[((size_t)b * Tn + p) * d + c] += pe;
-            }
-    }
-    int half = (cfg->fusion_layers - 1) / 2, Tcur = Tn;
-    float *f = tok;
-    for (int l = 0; l < (cfg->fusion == 1 ? 0 : cfg->fusion_layers); ++l) {
-        float *nf = mha_block(f, B, Tcur, d, l, l == half ? NJ : 0, &Tcur);
-        free(f);
-        f = nf;
-    }
-    if (fused_out) memcpy(fused_out, f, sizeof(float) * (size_t)B * NJ * d);
-    /* ---- decoder: nets.py:133-139 / 150-154 */
-    if (cfg->use_gcn) {
-        float *g1 = falloc((size_t)B * NJ * 256), *g2 = falloc((size_t)B * NJ * 64);
-        cheb_conv(f, B, d, 256, "joints_decoder.joints_gcn1", 1, g1);
-        cheb_conv(g1, B, 256, 64, "joints_decoder.joints_gcn2", 1, g2);
-        cheb_conv(g2, B, 64, 3, "joints_decoder.joints_gcn3", 0, joints_cam);
-        free(g1);
-        free(g2);
-    } else {
-        float *g1 = falloc((size_t)B * NJ * 64);
-        linear(f, B * NJ, d, T("joints_decoder.joints_fc1.weight")->data, T("joints_decoder.joints_fc1.bias")->data, 64, g1);
-        for (size_t i = 0; i < (size_t)B * NJ * 64; ++i) g1[i] = g1[i] < 0.f ? 0.01f * g1[i] : g1[i];
-        linear(g1, B * NJ, 64, T("joints_decoder.joints_fc2.weight")->data, T("joints_decoder.joints_fc2.bias")->data, 3,
-               joints_cam);
-        free(g1);
-    }
-    free(f);
+    fuse_and_decode(cfg, B, d, tok, fused_out, joints_cam);
     /* ---- handmvnet.py:252: joint_coords * image_size / heatmap_size */
     for (size_t i = 0; i < (size_t)N * NJ * 2; ++i)
         joints_crop_img[i] = coords[i] * (float)cfg->image_size / (float)cfg->heatmap_size;

@@ -70,6 +70,7 @@ def _lib(acc: str) -> ctypes.CDLL:
         lib = ctypes.CDLL(path)
         lib.hmvo_last_error.restype = ctypes.c_char_p
         lib.hmvo_forward.restype = ctypes.c_int
+        lib.hmvo_fuse_tokens.restype = ctypes.c_int
         lib.hmvo_set_num_threads(min(usable_cpus(), 64))
         _LIBS[acc] = lib
     return _LIBS[acc]
@@ -142,4 +143,18 @@ class Oracle:
         if rc:
             raise RuntimeError(f"oracle forward failed ({rc}): " + self.lib.hmvo_last_error().decode())
         out.update(st)
+        return out
+
+    def fuse_tokens(self, tokens: np.ndarray) -> Dict[str, np.ndarray]:
+        """The tail alone (handmvnet.py:225-229): joints_late_fusion + joints_decoder on a token matrix [B, V*21, d] supplied by the
+        caller -- e.g. the one the implementation under test captured -- so that its tail is checked apart from the conditioning of
+        everything in front of the tokens.  -> {"fused" [B,21,d], "joints_cam" [B,21,3]}."""
+        cfg = self.cfg
+        tokens = np.ascontiguousarray(tokens, dtype=np.float32)
+        B, T, d = tokens.shape
+        assert T == cfg.num_views * 21 and d == cfg.feat_dim, (tokens.shape, cfg.num_views, cfg.feat_dim)
+        out = {"fused": np.zeros((B, 21, d), np.float32), "joints_cam": np.zeros((B, 21, 3), np.float32)}
+        rc = self.lib.hmvo_fuse_tokens(ctypes.byref(self._c), B, _fp(tokens), _fp(out["fused"]), _fp(out["joints_cam"]))
+        if rc:
+            raise RuntimeError(f"oracle fuse_tokens failed ({rc}): " + self.lib.hmvo_last_error().decode())
         return out

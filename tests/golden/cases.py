@@ -31,6 +31,10 @@ CASES = {
     # HRNet-w40 / w64 backbones (6 of the 12 release configs use w40): 4 sampled levels, pose_net = 3x3 s2 conv
     "hr40_tiny": dict(bt="w40", ch=[40, 80, 160, 320], V=2, B=1, size=64, pos=ALL_POS, gcn=True, wseed=12, iseed=22),
     "hr40_v4_128": dict(bt="w40", ch=[40, 80, 160, 320], V=4, B=2, size=128, pos=["pos2d", "sin"], gcn=True, wseed=15, iseed=25),
+    # the *_HR release configs' shape (configs/release/*_HR*.yaml: w40, four levels, 256 x 256; 8 views as DexYCB): one sample.
+    # Sample 0 of a larger batch drawn with the same input seed has the same frames (synth_inputs is a counter hash), so this
+    # fixture also pins sample 0 of the 72-frame forward of test_hrnet_release_shape
+    "hr40_v8_256": dict(bt="w40", ch=[40, 80, 160, 320], V=8, B=1, size=256, pos=ALL_POS, gcn=True, wseed=16, iseed=26),
     "hr64_tiny": dict(bt="w64", ch=[64, 128, 256, 512], V=2, B=1, size=64, pos=ALL_POS, gcn=False, wseed=14, iseed=24),
     # non-power-of-two input, config constants that differ from the tensor shapes (handmvnet.py:252 quirk)
     "r50_odd_96": dict(bt="50_paper", ch=[1024], V=5, B=1, size=96, pos=ALL_POS, gcn=True, wseed=9, iseed=19,

@@ -135,10 +135,16 @@ def run_case(name: str, spec: dict, check_oracle: bool = True) -> dict:
                 setattr(mod, k, v)
             fus.float()
         fx["cond_fused32_vs_64"] = np.float64(rl(stages["fused"], f64))   # the reference's own fp32 run vs its float64 fusion
+        # ... and the same for the pose: the reference's fp32 forward vs its float64 fusion -> decoder on the same tokens.  The tests
+        # cap the conditioning-scaled tolerance with a small multiple of these two (how far fp32 itself sits from float64 here)
+        fx["cond_joints_cam32_vs_64"] = np.float64(rl(out["joints_cam"], cam64))
+        # the WHOLE token matrix of the reference run (small: B x V*21 x d floats): lets a test run a tail (fusion + decoder) on exactly
+        # the reference's tokens and compare with the reference's own tail, with the conditioning of everything in front taken out
+        fx["tokens_full"] = stages["tokens"].numpy().copy()
         fx["amp_fused"] = np.float64(max(amp_f))
         fx["amp_joints_cam"] = np.float64(max(amp_c))
         print(f"  conditioning: d(fused)/d(tokens) up to {fx['amp_fused']:.0f}, d(joints_cam)/d(tokens) up to {fx['amp_joints_cam']:.0f}; "
-              f"reference fp32 fused vs its float64 fusion {fx['cond_fused32_vs_64']:.3e}")
+              f"reference fp32 fused vs its float64 fusion {fx['cond_fused32_vs_64']:.3e}, joints_cam {fx['cond_joints_cam32_vs_64']:.3e}")
     if check_oracle:
         from oracle.oracle import Oracle
         for acc in ("f32", "f64"):

@@ -20,6 +20,26 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.hmv_version()
 
 
+def test_product_library_reads_one_environment_variable():
+    """Development knobs (A/B switches, probes) exist only in a -DHMV_DEV_KNOBS build: a stray HMV_* variable on a user's box must
+    not be able to change kernels, K orders or numerics.  Every "HMV_[A-Z0-9_]+" token in the product library's bytes is either the
+    one variable it reads (HMV_GRAPHS) or an enum name quoted in an error message / an assertion text."""
+    if os.environ.get("HMV_LIB"):
+        return   # an A/B run against another build (possibly the -dev one): nothing to assert about that file
+    data = open(_lib.LIB_PATH, "rb").read()
+    tokens = set(m.decode() for m in re.findall(rb"HMV_[A-Z0-9_]+[a-z0-9]*", data))
+    allowed = {"HMV_GRAPHS", "HMV_F32", "HMV_F16", "HMV_F32X3", "HMV_POS_SIN"}
+    assert tokens <= allowed, sorted(tokens - allowed)
+    assert "HMV_GRAPHS" in tokens
+    # and the sources spell every other knob through the gated macro
+    for f in os.listdir(os.path.join(ROOT, "handmvnet_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            text = open(os.path.join(ROOT, "handmvnet_amd", "csrc", f)).read()
+            for m in re.finditer(r"(?<![A-Za-z_])getenv\(\s*\"(\w+)\"", text):
+                assert m.group(1) == "HMV_GRAPHS", (f, m.group(1))
+    assert b"f32x3" in _lib.load().hmv_version() and b"f16" in _lib.load().hmv_version()
+
+
 def test_config_struct_matches_header_and_is_validated():
     lib = _lib.load()
     assert ctypes.sizeof(_lib.HmvConfig) == 18 * 4          # incl. the fusion kind added for cross_attn_learnable_query

@@ -47,7 +47,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, batch, q):
+def _worker(rank, world, port, port2, case, batch, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -87,6 +87,23 @@ def _worker(rank, world, port, case, batch, q):
         ptr = g.send.data_ptr()
         g3 = gather_outputs(local, total=batch)
         assert g.send.data_ptr() == ptr and g.collectives == 3 and torch.equal(g3["joints_cam"], out["joints_cam"])
+        # errors are raised (not asserted: `python -O`), BEFORE any collective is entered
+        with pytest.raises(ValueError, match="gathers"):
+            gather_outputs(local, total=batch, keys=("joints_cam", "heatmap"))
+        wrong = {"joints_cam": torch.zeros(n_max + 1, 21, 3), "joints_crop_img": torch.zeros(n_max + 1, xt.shape[1], 21, 2)}
+        with pytest.raises(ValueError, match="does not fit"):
+            g.gather(wrong, total=batch)
+        assert calls["n"] == 3, calls
+        only_cam = gather_outputs(local, total=batch, keys=("joints_cam",))
+        assert list(only_cam) == ["joints_cam"] and torch.equal(only_cam["joints_cam"], out["joints_cam"])
+        # a new process group (destroy + init) must not be served the old group's gatherer
+        dist.destroy_process_group()
+        os.environ["MASTER_PORT"] = str(port2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        gnew = gatherer_for(n_max, xt.shape[1], xt.device)
+        assert gnew is not g and gnew.collectives == 0
+        g4 = gather_outputs(local, total=batch)
+        assert torch.equal(g4["joints_cam"], out["joints_cam"])
         if rank == 0:
             q.put({k: v.numpy() for k, v in out.items()})
     finally:
@@ -98,8 +115,8 @@ def test_two_rank_gloo_matches_single_process(batch):
     case, world = "tiny_r50", 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, batch, q)) for r in range(world)]
+    port, port2 = _free_port(), _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, port2, case, batch, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)

@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from cases import CASES
-from helpers import check_against_fixture, load_case, rel_l2
+from helpers import check_against_fixture, cond_bounds, load_case, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -151,6 +151,131 @@ def test_fused_tail_kernels_match_the_unfused_launches(name):
     assert rep["fused"] <= 2e-5 and rep["joints_cam"] <= 2e-5, rep
     assert np.array_equal(fused["tokens"], plain["tokens"])
     assert n_fused < n_plain, (n_fused, n_plain)
+
+
+TAIL_CASES = ["hr40_lq", "r50_lq", "r18_lq_wocam", "cfg3s_r50_v8_256", "tiny_r18", "hr40_tiny", "r50_wocam_nn", "r18_13views",
+              "r18_single_view", "r18_frozen_nosin"]
+TOL_TAIL_FUSED, TOL_TAIL_CAM = 5e-5, 2e-4
+
+
+def _set_mode(m, mode):
+    if mode == "f16":
+        m.half()
+    elif mode == "f32x3":
+        m.float32x3()
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16", "f32x3"])
+@pytest.mark.parametrize("name", TAIL_CASES)
+def test_fusion_tail_on_engine_tokens(name, mode):
+    """Implementation error apart from conditioning: the engine's OWN captured token matrix goes through the f64
+    oracle's fusion + decoder (oracle.fuse_tokens), and the engine's `fused` / joints_cam must match THAT -- at a quarter of the
+    stage bar / a fifth of the north-star bar (the tail alone, no backbone noise amplified through it), or, for fixtures of
+    ill-conditioned configurations, at 4 x the distance of the reference's own fp32 run from its float64 evaluation (hr40_lq:
+    3.0e-4 / 7.1e-4 where worst-case amplification x token error would allow 1e-2 .. 1).  In every arithmetic mode the tail is
+    fp32 (the fp16 path's q/k/v projections run as (hi, lo) pairs), so the fp16 path's learnable-query tail is pinned here even where
+    its end-to-end joints_cam floor is vacuous (fp16_noise.json: hr40_lq 1.1)."""
+    from oracle.oracle import Oracle
+    m, cfg, sd, (x, bbox, intr), fx = _model(name)
+    _set_mode(m, mode)
+    got = _run(m, x, bbox, intr)
+    ref = Oracle(cfg, sd, "f64").fuse_tokens(got["tokens"])
+    tol_cam, tol_fused = cond_bounds(fx, TOL_TAIL_CAM, TOL_TAIL_FUSED)
+    rep = {"fused": rel_l2(got["fused"], ref["fused"]), "joints_cam": rel_l2(got["joints_cam"], ref["joints_cam"]),
+           "bounds": (tol_fused, tol_cam)}
+    print(name, mode, rep)
+    assert rep["fused"] <= tol_fused and rep["joints_cam"] <= tol_cam, rep
+
+
+@pytest.mark.parametrize("mode", ["f32", "f32x3", "f16"])
+def test_hrnet_release_shape(mode):
+    """The *_HR release configs' shape (configs/release/*_HR*.yaml; hrnet.py:372-407): HRNet-w40, levels [40, 80, 160, 320],
+    V = 8, 256 x 256, B = 9 -> 72 frames, above every size gate of the engine (conv_rds_f32, conv_hs<40|80>, the 256 x 192 tile,
+    the >= 65 536-pixel tile rules, the layer1 chain), which the 128 x 128 HRNet fixtures never reach.  Sample 0 against the
+    fixture of the REAL reference (hr40_v8_256: the same frames, synth_inputs is a counter hash) and against the f64 oracle at
+    the mode's bar; samples 0, 4, 8 bit-equal to their single-sample runs; everything finite."""
+    from handmvnet_amd import HandMvNet
+    from handmvnet_amd.synth import synth_inputs
+    from oracle.oracle import Oracle
+    cfg, (tp, mp, dp), sd, (x1, bbox1, intr1), fx = load_case("hr40_v8_256")
+    m = HandMvNet(tp, mp, dp)
+    m.load_state_dict(sd, strict=True)
+    m.to("cuda").eval()
+    _set_mode(m, mode)
+    spec = CASES["hr40_v8_256"]
+    x, bbox, intr = synth_inputs(cfg, 9, spec["iseed"], 256)
+    assert np.array_equal(x[:1], x1) and np.array_equal(bbox[:1], bbox1) and np.array_equal(intr[:1], intr1)
+    got = _run(m, x, bbox, intr)
+    for k in ("joints_cam", "joints_crop_img", "heatmap", "feat0", "tokens", "fused"):
+        assert np.isfinite(got[k]).all(), k
+    assert got["heatmap"].shape == (9, 8, 21, 32, 32) and got["feat0"].shape[0] == 72
+    for i in (0, 4, 8):
+        one = _run(m, x[i:i + 1], bbox[i:i + 1], intr[i:i + 1])
+        for k in ("joints_cam", "joints_crop_img", "heatmap"):
+            assert np.array_equal(one[k][0], got[k][i]), (mode, i, k)
+        if i == 0:
+            first = one
+    # sample 0 vs the real reference's fixture (stages of the B = 1 run have the fixture's shapes) ...
+    ref = Oracle(cfg, sd, "f64").forward(x[:1], bbox[:1], intr[:1], stages=True)
+    if mode == "f16":
+        bound = fp16_bounds("hr40_v8_256")
+        hm = rel_l2(first["heatmap"].reshape(-1)[fx["heatmap_idx"]], fx["heatmap_val"])
+        feat = rel_l2(first["feat0"].reshape(-1)[fx["feat0_idx"]], fx["feat0_val"])
+        dc = np.abs(first["coords_hm"] - fx["coords_hm"])
+        cam = rel_l2(first["joints_cam"], fx["joints_cam"])
+        rep = {"feat0": feat, "heatmap": hm, "coord_median_px": float(np.median(dc)), "coord_flip_frac": float((dc > 0.5).mean()),
+               "joints_cam": cam, "bounds": bound}
+        print(mode, rep)
+        assert feat <= 2e-3 and hm <= bound["heatmap"], rep
+        assert rep["coord_median_px"] <= 0.02 and rep["coord_flip_frac"] <= bound["flip"], rep
+        assert cam <= bound["joints_cam"], rep
+    else:
+        rep = check_against_fixture(first, fx, tol_cam=TOL_CAM, tol_coord_px=0.05 * cfg.image_size / cfg.heatmap_size, tol_stage=TOL_STAGE)
+        rep["coords"] = float(np.abs(first["coords_hm"] - fx["coords_hm"]).max())
+        # ... and vs the f64 oracle (whole tensors, not samples of them)
+        rep["oracle"] = {k: rel_l2(first[k], ref[k]) for k in ("joints_cam", "heatmap", "feat0", "tokens", "fused")}
+        print(mode, rep)
+        assert rep["coords"] < 0.05, rep
+        assert rep["oracle"]["joints_cam"] <= TOL_CAM and max(rep["oracle"][k] for k in ("heatmap", "feat0", "tokens", "fused")) <= TOL_STAGE, rep
+
+
+# (backbone_type, channels, V, B, size): frame sizes that do and do not tile into the size-gated kernels' blocks (conv_ht 16 x 32,
+# conv_hs 16 x 16 / 8 x 16, conv_stream's pixel tiles, conv_rds' 64-pixel rows), at batches above their gates
+SIZE_ROWS = [("w40", [40, 80, 160, 320], 2, 8, 320), ("50_paper", [1024], 4, 20, 192), ("50_paper", [1024], 4, 16, 320),
+             ("50_paper", [1024], 2, 6, 512)]
+
+
+@pytest.mark.parametrize("row", SIZE_ROWS, ids=lambda r: f"{r[0]}-V{r[2]}-B{r[3]}-{r[4]}")
+def test_size_gated_kernels_at_other_frame_sizes(row):
+    """tools/size_smoke.py's rows as assertions: fp32 and fp16 forwards at frame sizes other than 256 x 256 with
+    batches large enough for the persistent / tall-tile kernels -- finite, a sample alone == the same sample inside the batch bit
+    for bit in both modes (an engine-level stride or packing slip at these sizes breaks exactly that), and the fp16 pose within
+    the fp16-storage noise level of the fp32 one (0.05 .. 0.13 measured in round 3; a layout slip is O(1))."""
+    from cases import case_params
+    from handmvnet_amd import HandMvNet
+    from handmvnet_amd.spec import config_from_params
+    from handmvnet_amd.synth import synth_inputs, synth_state_dict
+    bt, ch, V, B, size = row
+    spec = dict(bt=bt, ch=ch, V=V, B=B, size=size, pos=["pos2d", "crop", "sin"], gcn=True, wseed=3, iseed=11)
+    tp, mp, dp = case_params(spec)
+    cfg = config_from_params(tp, mp, dp)
+    m = HandMvNet(tp, mp, dp)
+    m.load_state_dict(synth_state_dict(cfg, 3), strict=True)
+    m.to("cuda").eval()
+    x, bbox, intr = synth_inputs(cfg, B, 11, size)
+    res = {}
+    for mode in ("f32", "f16"):
+        _set_mode(m, mode)
+        out = _run(m, x, bbox, intr, stages=False)
+        last = B - 1
+        one = _run(m, x[last:], bbox[last:], intr[last:], stages=False)
+        for k in ("joints_cam", "joints_crop_img", "heatmap"):
+            assert np.isfinite(out[k]).all(), (mode, k)
+            assert np.array_equal(one[k][0], out[k][last]), (mode, k)
+        res[mode] = out["joints_cam"]
+    rel = rel_l2(res["f16"], res["f32"])
+    print(row, "fp16 vs fp32 joints_cam rel-L2", rel)
+    assert rel < 0.3, rel
 
 
 CONV_SHAPES = [
@@ -548,7 +673,16 @@ def test_full_size_properties(mode):
     # the fp16 path at its noise-floor bound (same model as the cfg3s fixture)
     ref = Oracle(cfg, sd, "f64").forward(x[:1], bbox[:1], intr[:1])
     cam = rel_l2(a["joints_cam"][0].cpu().numpy(), ref["joints_cam"][0])
-    assert cam <= (fp16_bounds("cfg3s_r50_v8_256")["joints_cam"] if mode == "f16" else TOL_CAM), (mode, cam)
+    hm = rel_l2(a["heatmap"][0].cpu().numpy(), ref["heatmap"][0])
+    dc = np.abs(a["joints_crop_img"][0].cpu().numpy() - ref["joints_crop_img"][0]) / 8.0       # heat-map px
+    rep = {"joints_cam": cam, "heatmap": hm, "coord_median_px": float(np.median(dc)), "coord_flip_frac": float((dc > 0.5).mean())}
+    print(mode, rep)
+    if mode == "f16":      # the fp16 path at the fp16-storage floor of this model (fixture cfg3s_r50_v8_256), heat map and coordinates too
+        bound = fp16_bounds("cfg3s_r50_v8_256")
+        assert cam <= bound["joints_cam"] and hm <= bound["heatmap"], (rep, bound)
+        assert rep["coord_median_px"] <= 0.02 and rep["coord_flip_frac"] <= bound["flip"], (rep, bound)
+    else:
+        assert cam <= TOL_CAM and hm <= TOL_STAGE and dc.max() < 0.05, (mode, rep)
 
 
 @pytest.mark.parametrize("case,frames_per_sample,fewer,size,samples", [("cfg3s_r50_v8_256", 8, 4, 256, (4, 5)), ("hr40_v4_128", 4, 3, 256, (8, 9)),
@@ -689,7 +823,15 @@ def test_fp16_path_within_its_stated_tolerance(name):
     # flips are discrete events on near-tied peaks: on a small case (84 coordinate values) 2 % is less than two of them, and which
     # ties flip changes with the summation order of the fp16 products (the heat-map error itself stays at the floor): allow four values
     assert rep["coord_median_px"] <= 0.02 and rep["coord_flip_frac"] <= max(bound["flip"], bound["flip"] - 0.02 + 4.0 / dc.size), rep
-    assert cam <= bound["joints_cam"], rep
+    if "amp_joints_cam" in fx:
+        # ill-conditioned by construction (hr40_lq: the module amplifies token noise up to 6 000 x; the fp16-storage floor measured on
+        # the reference is 1.1, i.e. a bound an all-zero pose would pass): the END-TO-END fp16 pose of this case is NOT pinned -- said
+        # here instead of asserting a vacuous number.  What is pinned: backbone features, heat map and coordinates above, and the
+        # fusion + decoder tail on the engine's own fp16-path tokens at fp32-grade bars (test_fusion_tail_on_engine_tokens[...-f16]).
+        print(name, "joints_cam of the fp16 path: parity unpinned (conditioning); tail pinned by test_fusion_tail_on_engine_tokens")
+    else:
+        assert bound["joints_cam"] < 0.5, bound
+        assert cam <= bound["joints_cam"], rep
     assert np.isfinite(got["joints_cam"]).all()
     # and the fp16 engine really is a different numerical path from the fp32 one
     m.float()
@@ -706,7 +848,7 @@ def test_fp16_path_within_its_stated_tolerance(name):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["tiny_r50", "cfg1_r50_v4_128", "cfg3s_r50_v8_256", "r50_wocam_nn", "r50_odd_96",
                                   "hr40_tiny", "hr40_v4_128", "hr64_tiny", "tiny_r18", "cfg2s_r18_v4_256", "r34_onelevel",
-                                  "r18_frozen_nosin", "r18_single_view", "r18_13views", "r50_lq", "r18_lq_wocam", "r50_200", "r18_100", "hr40_lq"])
+                                  "r18_frozen_nosin", "r18_single_view", "r18_13views", "r50_lq", "r18_lq_wocam", "r50_200", "r18_100", "hr40_lq", "hr40_v8_256"])
 def test_split_precision_path_meets_the_fp32_bar(name):
     m, cfg, sd, (x, bbox, intr), fx = _model(name)
     m.float32x3()
@@ -849,7 +991,8 @@ LQ_ATTENTION_SHAPES = [(2, 42, 42, False), (1, 168, 168, False), (3, 63, 21, Tru
 @pytest.mark.parametrize("shape", LQ_ATTENTION_SHAPES)
 def test_lq_attention_kernel_vs_torch(shape):
     """op-level: the learnable-query fusion's attention (layers.py:284-291, 8 heads x 256) on the fp32 matrix cores vs torch fp64,
-    sharp rows included; the MFMA kernel and the round-2 scalar kernel (HMV_LQ_SCALAR_ATT=1) must agree; batch independence."""
+    sharp rows included; batch independence.  (The round-2 scalar kernel it was first checked against is reachable only in a
+    -DHMV_DEV_KNOBS build now.)"""
     from handmvnet_amd import _lib
     lib = _lib.load()
     B, T, Tq, probe = shape
@@ -882,12 +1025,6 @@ def test_lq_attention_kernel_vs_torch(shape):
     tol = 4e-6 * max(ref.abs().max().item(), 1.0)
     assert (got.cpu().double() - ref).abs().max().item() < tol
     assert torch.equal(run(1)[0], got[0])                 # sample 0 alone gives the same bits
-    os.environ["HMV_LQ_SCALAR_ATT"] = "1"
-    try:
-        old = run(B)
-    finally:
-        del os.environ["HMV_LQ_SCALAR_ATT"]
-    assert (old.cpu().double() - ref).abs().max().item() < tol
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16", "f32x3"])

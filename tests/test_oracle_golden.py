@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from cases import CASES
-from helpers import check_against_fixture, load_case
+from helpers import check_against_fixture, cond_bounds, load_case, rel_l2
 from oracle.oracle import Oracle
 
 SMALL = [c for c in CASES if c not in ("cfg3s_r50_v8_256",)]
@@ -19,7 +19,9 @@ SMALL = [c for c in CASES if c not in ("cfg3s_r50_v8_256",)]
 def test_oracle_f32_matches_reference(name):
     cfg, _, sd, (x, bbox, intr), fx = load_case(name)
     out = Oracle(cfg, sd, "f32").forward(x, bbox, intr, stages=True)
-    rep = check_against_fixture(out, fx, tol_cam=3e-4, tol_coord_px=0.05, tol_stage=1e-4)
+    # cond_cap: for the ill-conditioned fixture (hr40_lq) the END-TO-END allowance is 12 x the reference's own fp32-vs-float64
+    # distance (the oracle's token error, 2.9e-6, is amplified ~600 x there: joints_cam 1.7e-3); its tail alone is held to 4 x below
+    rep = check_against_fixture(out, fx, tol_cam=3e-4, tol_coord_px=0.05, tol_stage=1e-4, cond_cap=12.0)
     assert np.abs(out["coords_hm"] - fx["coords_hm"]).max() < 5e-3, rep
 
 
@@ -28,6 +30,25 @@ def test_oracle_f64_matches_reference(name):
     cfg, _, sd, (x, bbox, intr), fx = load_case(name)
     out = Oracle(cfg, sd, "f64").forward(x, bbox, intr, stages=True)
     check_against_fixture(out, fx, tol_cam=3e-4, tol_coord_px=0.05, tol_stage=1e-4)
+
+
+@pytest.mark.parametrize("acc", ["f32", "f64"])
+def test_oracle_tail_on_the_reference_tokens(acc):
+    """The fusion + decoder tail ALONE, fed with the reference run's own token matrix (fixtures of ill-conditioned configurations
+    carry it whole): with the conditioning of everything in front of the tokens taken out, the oracle's tail must sit as close to the
+    reference's tail as the reference's fp32 run sits to its own float64 evaluation (x 4), not "amplification x token error"."""
+    cfg, _, sd, _, fx = load_case("hr40_lq")
+    tol_cam, tol_fused = cond_bounds(fx, 3e-4, 1e-4)
+    assert tol_cam <= 1e-3 and tol_fused <= 3e-4
+    o = Oracle(cfg, sd, acc)
+    t = o.fuse_tokens(fx["tokens_full"])
+    assert rel_l2(t["fused"].reshape(-1)[fx["fused_idx"]], fx["fused_val"]) <= tol_fused
+    assert rel_l2(t["joints_cam"], fx["joints_cam"]) <= tol_cam
+    # the tail entry is the forward's own tail: same bits from the same tokens
+    x, bbox, intr = load_case("hr40_lq")[3]
+    e = o.forward(x, bbox, intr, stages=True)
+    t2 = o.fuse_tokens(e["tokens"])
+    assert np.array_equal(t2["fused"], e["fused"]) and np.array_equal(t2["joints_cam"], e["joints_cam"])
 
 
 def test_oracle_reports_missing_weight():

@@ -27,6 +27,14 @@
 //     Half-tiles are cut along the phase boundaries: pixel half h = blocks 2h, 2h + 1 of both wave rows; weight half h =
 //     block h of all four wave columns.
 // Operand roles, bias-as-initial-accumulator and the register epilogue are conv_igemm's transposed-output path.
+//
+// Round 4: M16 = the same tile, schedule and LDS image on v_mfma_f32_16x16x32_f16 (12-15 % less time on conv_ht's MFMA-bound loop at equal
+// cycles, profiles/r04_probe_mfma_shape.txt).  A phase's 8 MFMAs of 32 cycles become 16 of 16: pixel blocks a, a + 1 are four 16-row
+// blocks, channel block b two, the 64-wide k-step two k32 groups (ascending); a lane's fragment is k-group lane >> 4 of row lane & 15
+// (chunk 4 g + kg of the 128-byte row: the (row >> 1) & 7 swizzle keeps a ds_read_b128's 16-lane groups conflict-free for this map too).
+// LDS weight row 16 e + rho of a 32-channel block holds channel 8 (rho >> 2) + 4 e + (rho & 3) (source-side permutation), which makes a
+// lane's two 16-row blocks 8 consecutive channels.  The layers that take it are chosen by SHAPE (conv_m16_rule), never by the batch:
+// their small launches run conv_m16.hip's tiles, same bits.
 #include <cstdio>
 #include <cstdlib>
 
@@ -43,8 +51,9 @@ typedef _Float16 gf16x8 __attribute__((ext_vector_type(8)));
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
 // DUAL: the reduction is the concatenation [first source | second source] (conv3 + downsample as one GEMM, ConvParams::in2)
-template <bool DUAL>
+template <bool DUAL, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void conv_gemm8_f16(const ConvParams p) {
+    static_assert(!(DUAL && M16), "the 16x16x32 form is built for single-source launches");
     constexpr int HT = 128 * 64;   // halfs per half-tile
     extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];   // [2 k-steps][A0, A1, B0, B1][128][64]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -91,7 +100,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8_f16(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int hr = (tid >> 3) + 64 * i;
-            wsrc[h][i] = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(nt * 256 + (hr >> 5) * 64 + h * 32 + (hr & 31)) * p.ldw + 8 * kqs;
+            const int line = hr & 31, ch = M16 ? 8 * ((line & 15) >> 2) + 4 * (line >> 4) + (line & 3) : line;
+            wsrc[h][i] = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(nt * 256 + (hr >> 5) * 64 + h * 32 + ch) * p.ldw + 8 * kqs;
         }
     const _Float16 *Ain = reinterpret_cast<const _Float16 *>(p.in), *Ain2 = reinterpret_cast<const _Float16 *>(p.in2);
 
@@ -118,43 +128,73 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8_f16(const ConvParams p) {
         }
     };
 
-    // ---- accumulators start at the bias (transposed output: a register is ONE channel for all of the lane's pixels)
-    gf32x16 acc[4][2];
+    // ---- accumulators start at the bias (transposed output: a register is ONE channel for all of the lane's pixels).
+    // 16x16x32: acc4[a][s][b][e] = pixel rows 32 a + 16 s + l15, 16-row weight block e of channel block b: register r = channel
+    // 32 b + 8 kg + 4 e + r
+    gf32x16 acc[M16 ? 1 : 4][M16 ? 1 : 2];
+    gf32x4 acc4[M16 ? 4 : 1][M16 ? 2 : 1][M16 ? 2 : 1][M16 ? 2 : 1];
+    const int l15 = lane & 15, kg = lane >> 4;
     {
         const float binit = 1.f / p.acc_scale;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const float *bp = p.bias + nt * 256 + wn * 64 + 32 * b;
+            if constexpr (!M16) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const gf32x4 bq = *reinterpret_cast<const gf32x4 *>(bp + 16 * (q >> 1) + 8 * kh + 4 * (q & 1));
+                for (int q = 0; q < 4; ++q) {
+                    const gf32x4 bq = *reinterpret_cast<const gf32x4 *>(bp + 16 * (q >> 1) + 8 * kh + 4 * (q & 1));
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[a][b][4 * q + u] = bq[u] * binit;
+                        for (int u = 0; u < 4; ++u) acc[a][b][4 * q + u] = bq[u] * binit;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const gf32x4 bq = *reinterpret_cast<const gf32x4 *>(bp + 8 * kg + 4 * e);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) acc4[a][sb][b][e][u] = bq[u] * binit;
+                }
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias loads: the counted waits below see DMAs only
 
     // fragment addresses: pixel block a -> half a >> 1, half-row wm * 64 + (a & 1) * 32 + l31; weight block b -> half b,
-    // half-row wn * 32 + swap23(l31) (the row swap makes registers 8j .. 8j+7 eight consecutive channels)
+    // half-row wn * 32 + swap23(l31) (the row swap makes registers 8j .. 8j+7 eight consecutive channels).
+    // 16x16x32: rows ... + 16 s + l15 resp. wn * 32 + 16 e + l15 (the channel permutation sits in the DMA source), chunks 4 g + kg
     const int wl31 = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-    const int fsw = (l31 >> 1) & 7, fswb = (wl31 >> 1) & 7;
-    const int prow = (wm * 64 + l31) * 64, wrow = (wn * 32 + wl31) * 64;
-    gf16x8 fa[2][4], fb0[4], fb1[4];
+    const int fsw = M16 ? (l15 >> 1) & 7 : (l31 >> 1) & 7, fswb = M16 ? (l15 >> 1) & 7 : (wl31 >> 1) & 7;   // (rows + 16 s: (row >> 1) & 7 is unchanged)
+    const int prow = (wm * 64 + (M16 ? l15 : l31)) * 64, wrow = (wn * 32 + (M16 ? l15 : wl31)) * 64;
+    gf16x8 fa[2][4], fb0[4], fb1[4];   // 16x16x32: fa[a][2 s + g], fb[2 e + g]
 #define G8_READ_P(t, h)                                                                                     \
     _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                                        \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                    \
-            fa[a_][q_] = *reinterpret_cast<const gf16x8 *>(gsm + (((t) & 1) * 4 + (h)) * HT + prow + a_ * 32 * 64 + (((2 * q_ + kh) ^ fsw) * 8));
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
+            if constexpr (!M16) fa[a_][q_] = *reinterpret_cast<const gf16x8 *>(gsm + (((t) & 1) * 4 + (h)) * HT + prow + a_ * 32 * 64 + (((2 * q_ + kh) ^ fsw) * 8)); \
+            else fa[a_][q_] = *reinterpret_cast<const gf16x8 *>(gsm + (((t) & 1) * 4 + (h)) * HT + prow + (a_ * 32 + (q_ >> 1) * 16) * 64 + (((4 * (q_ & 1) + kg) ^ fsw) * 8)); \
+        }
 #define G8_READ_W(t, h, FB)                                                                                 \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                        \
-        FB[q_] = *reinterpret_cast<const gf16x8 *>(gsm + (((t) & 1) * 4 + 2 + (h)) * HT + wrow + (((2 * q_ + kh) ^ fswb) * 8));
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                      \
+        if constexpr (!M16) FB[q_] = *reinterpret_cast<const gf16x8 *>(gsm + (((t) & 1) * 4 + 2 + (h)) * HT + wrow + (((2 * q_ + kh) ^ fswb) * 8)); \
+        else FB[q_] = *reinterpret_cast<const gf16x8 *>(gsm + (((t) & 1) * 4 + 2 + (h)) * HT + wrow + (q_ >> 1) * 16 * 64 + (((4 * (q_ & 1) + kg) ^ fswb) * 8)); \
+    }
 #define G8_MFMA(A0, B, FB)                                                                                  \
     __builtin_amdgcn_s_setprio(1);                                                                          \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                        \
-        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                                    \
-            acc[(A0) + a_][B] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FB[q_], fa[a_][q_], acc[(A0) + a_][B], 0, 0, 0); \
+    if constexpr (!M16) {                                                                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                    \
+            _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                                \
+                acc[(A0) + a_][B] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FB[q_], fa[a_][q_], acc[(A0) + a_][B], 0, 0, 0); \
+    } else {                                                                                                \
+        _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_)                                                    \
+            _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                                \
+                _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                            \
+                    _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_)                                        \
+                        acc4[(A0) + a_][s_][B][e_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FB[2 * e_ + g_], fa[a_][2 * s_ + g_], acc4[(A0) + a_][s_][B][e_], 0, 0, 0); \
+    }                                                                                                       \
     __builtin_amdgcn_s_setprio(0);
 // raw barrier, no vmcnt / lgkmcnt: the DMAs stay in flight across it; the compiler itself waits (lgkmcnt) for the fragments an
 // MFMA reads, and sched_barrier(0) keeps the MFMA cluster between its two barriers
@@ -228,23 +268,40 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8_f16(const ConvParams p) {
 
     // ---- epilogue straight from the accumulators (conv_igemm's register path without a residual):
     //   register 8j + u of block (a, b) = channel 32 b + 16 j + 8 kh + u of pixel row 32 a + l31
+    //   16x16x32: registers of blocks (a, s, b, e = 0 / 1) = channels 32 b + 8 kg + 0 .. 7 of pixel row 32 a + 16 s + l15
     const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
     const int nb0 = nt * 256 + wn * 64;
     const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 7) & ~7);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const int m = mt * 256 + wm * 128 + 32 * a + l31;
-        _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc;
+        if constexpr (!M16) {
+            const int m = mt * 256 + wm * 128 + 32 * a + l31;
+            _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = nb0 + 32 * b + 16 * j + 8 * kh;
-                gf16x8 hv;
+                for (int j = 0; j < 2; ++j) {
+                    const int col = nb0 + 32 * b + 16 * j + 8 * kh;
+                    gf16x8 hv;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + 0.f, lo);
-                if (m < p.M && col < cend) *reinterpret_cast<gf16x8 *>(orow + col) = hv;
+                    for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + 0.f, lo);
+                    if (m < p.M && col < cend) *reinterpret_cast<gf16x8 *>(orow + col) = hv;
+                }
+        } else {
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const int m = mt * 256 + wm * 128 + 32 * a + 16 * sb + l15;
+                _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int col = nb0 + 32 * b + 8 * kg;
+                    gf16x8 hv;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc4[a][sb][b][u >> 2][u & 3] * p.acc_scale + 0.f, lo);
+                    if (m < p.M && col < cend) *reinterpret_cast<gf16x8 *>(orow + col) = hv;
+                }
             }
+        }
     }
 }
 
@@ -462,11 +519,17 @@ hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name) {
     if (!configured[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8_f16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8_f16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8_f16<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured[dev] = true;
     }
     p.mtiles = (p.M + 255) / 256;
     p.ntiles = (p.Cout + 255) / 256;
+    if (p.m16 && !p.in2) {   // the layer multiplies on the 16x16x32 MFMA at every batch size (conv_m16_rule: by shape)
+        if (name) *name = "conv_gemm8_f16<256x256,1x1,m16>";
+        hipLaunchKernelGGL((conv_gemm8_f16<false, true>), dim3(p.mtiles * p.ntiles), dim3(512), lds, s, p);
+        return hipGetLastError();
+    }
     if (name) *name = p.in2 ? "conv_gemm8_f16<256x256,1x1,dual>" : "conv_gemm8_f16<256x256,1x1>";
     // development knob, OFF by default: HMV_GEMM8_RING=1 selects conv_gemm8r_f16 (wave-specialised operand streams on a k32 ring).
     // Measured 6 % SLOWER than the four-phase loop (layer3 conv1 172 vs 162 us, profiles/r03_probe_gemm8_ring.txt): these launches are

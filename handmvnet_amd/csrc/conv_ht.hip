@@ -21,6 +21,13 @@
 //     takes, it takes at every batch size, and a sample's bits stay independent of its batch.  The engine packs those layers'
 //     weights in this order (Loader::conv, `tall`).
 // Operand roles, bias-as-initial-accumulator and the register epilogue are conv_igemm's transposed-output path.
+//
+// Round 4: the kernel is a template on the MFMA SHAPE (MI355X_MICROARCH.md "DVFS give-back" item 7: where the chip
+// lowers its clock under load, the clock it holds can depend on the shape).  M16 = v_mfma_f32_16x16x32_f16: the wave's 128 pixels x 64
+// channels are 8 x 4 blocks of 16 x 16, a k-step (one tap of one 32-channel sub-chunk) is ONE MFMA per block (32 MFMAs of 16 cycles
+// instead of 16 of 32), a lane's 16-byte fragment is k-group lane >> 4 of pixel / weight row lane & 15.  Same DMA schedule, same
+// LDS bytes read per step (12 ds_read_b128), same accumulator count; the LDS images are swizzled with another key (below) because
+// a ds_read_b128's 16-lane service groups then mix two k-groups.
 #include <cstdio>
 #include <cstdlib>
 
@@ -61,6 +68,16 @@ __device__ __forceinline__ void ht_wait() {   // ... and this wave's fragment re
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ht_after_w(TAP)) : "memory");
 }
 
+// LDS swizzle keys (XORed into the 16-byte chunk index of a 64-byte row).  32x32x16: (index >> 2) & 3 -- a read's 16 lanes are 16
+// consecutive pixels / rows of ONE k-half.  16x16x32: ((index >> 2) & 1) << 1 -- a read's 16-lane service group {0-3, 12-15, 20-27} is
+// pixels 0-3 and 12-15 of k-group g with pixels 4-11 of k-group g ^ 1; this key (found by exhaustive search over keys of period 8,
+// tools/probe/swizzle_search.py) keeps all 16 on distinct bank quads for the tap shifts 0, 1, 2 and for the weight rows' 8-row pitch.
+// Weight rows: a 16x16 block's fragment rows are 4-row groups 8 rows apart (the epilogue wants a lane's two blocks to hold 8
+// consecutive channels), so their key is ((row >> 3) & 1) << 1.
+template <bool M16> __device__ __forceinline__ int ht_pkey(int hx) { return M16 ? (((hx >> 2) & 1) << 1) : ((hx >> 2) & 3); }
+template <bool M16> __device__ __forceinline__ int ht_wkey(int row) { return M16 ? (((row >> 3) & 1) << 1) : ((row >> 2) & 3); }
+
+template <bool M16>
 __global__ __launch_bounds__(512) void conv_ht_f16(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char tsm[];   // [2 halo images][4 weight stages]
     char *wst = tsm + 2 * HT_IMG;
@@ -94,10 +111,10 @@ __global__ __launch_bounds__(512) void conv_ht_f16(const ConvParams p) {
         const int L = 512 * i + tid, hp = L >> 2, hy = hp / HT_HW, hx = hp - hy * HT_HW;
         const int iy = by * 16 - 1 + hy, ix = bx * 32 - 1 + hx;
         const bool ok = hp < HT_HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        hsrc[i] = ok ? reinterpret_cast<const _Float16 *>(p.in) + ((size_t)(n * p.H + iy) * p.W + ix) * p.lda + 8 * ((L & 3) ^ ((hx >> 2) & 3)) : nullptr;
+        hsrc[i] = ok ? reinterpret_cast<const _Float16 *>(p.in) + ((size_t)(n * p.H + iy) * p.W + ix) * p.lda + 8 * ((L & 3) ^ ht_pkey<M16>(hx)) : nullptr;
     }
     // weights: thread -> row tid >> 2 of the 128-row stage, physical chunk tid & 3 holding logical chunk (tid & 3) ^ ((row >> 2) & 3)
-    const _Float16 *wsrc = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(nt * 128 + (tid >> 2)) * p.ldw + 8 * ((tid & 3) ^ ((tid >> 4) & 3));
+    const _Float16 *wsrc = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(nt * 128 + (tid >> 2)) * p.ldw + 8 * ((tid & 3) ^ ht_wkey<M16>(tid >> 2));
 
     auto issue_w = [&](int s) {   // the weight stage of step s (past the end: a dummy from the zero page, nobody reads it)
         const _Float16 *src = s < nstep ? wsrc + 32 * s : zero16;
@@ -110,57 +127,98 @@ __global__ __launch_bounds__(512) void conv_ht_f16(const ConvParams p) {
         HMV_TGLDS16(src, tsm + (c & 1) * HT_IMG + i * 8192 + wave * 1024);
     };
 
-    // ---- accumulators start at the bias
-    tf32x16 acc[4][2];
+    // ---- accumulators start at the bias.  32x32x16: acc[a][b] = pixel row a x 32-channel block b, register 8 j + u = channel
+    // 32 b + 16 j + 8 kh + u.  16x16x32: acc4[a][h][cb] = pixel row a, column half h x 16-row block cb = 2 t + e, register u of lane
+    // group g = lane >> 4 = channel 32 t + 8 g + 4 e + u (so blocks 2 t, 2 t + 1 give a lane 8 consecutive channels)
+    tf32x16 acc[M16 ? 1 : 4][M16 ? 1 : 2];
+    tf32x4 acc4[M16 ? 4 : 1][M16 ? 2 : 1][M16 ? 4 : 1];
+    const int l15 = lane & 15, kg = lane >> 4;
     {
         const float binit = 1.f / p.acc_scale;
+        if constexpr (!M16) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const float *bp = p.bias + nt * 128 + wn * 64 + 32 * b;
+            for (int b = 0; b < 2; ++b) {
+                const float *bp = p.bias + nt * 128 + wn * 64 + 32 * b;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const tf32x4 bq = *reinterpret_cast<const tf32x4 *>(bp + 16 * (q >> 1) + 8 * kh + 4 * (q & 1));
+                for (int q = 0; q < 4; ++q) {
+                    const tf32x4 bq = *reinterpret_cast<const tf32x4 *>(bp + 16 * (q >> 1) + 8 * kh + 4 * (q & 1));
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[a][b][4 * q + u] = bq[u] * binit;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const tf32x4 bq = *reinterpret_cast<const tf32x4 *>(p.bias + nt * 128 + wn * 64 + 32 * (cb >> 1) + 8 * kg + 4 * (cb & 1));
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[a][b][4 * q + u] = bq[u] * binit;
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc4[a][h][cb][u] = bq[u] * binit;
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!M16) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(acc[a][b]));   // the bias is in the accumulators BEFORE the first DMA is issued
+            for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(acc[a][b]));   // the bias is in the accumulators BEFORE the first DMA is issued
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) asm volatile("" : "+v"(acc4[a][h][cb]));
+    }
 
-    // fragment addresses: pixel block a = image row 4 wm + a of the block, lane = column; weight block b = rows wn 64 + 32 b + swap23(l31)
+    // fragment addresses.  32x32x16: pixel block a = image row 4 wm + a of the block, lane = column; weight block b = rows
+    // wn 64 + 32 b + swap23(l31).  16x16x32: pixel block (a, h) = columns 16 h + l15 of that row, k-group kg; weight block cb = 2 t + e =
+    // rows wn 64 + 32 t + 8 (l15 >> 2) + 4 e + (l15 & 3), k-group kg
     const int wl31 = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-    const int wrow = wn * 64 + wl31, wsw = (wrow >> 2) & 3;   // (+ 32 b leaves (row >> 2) & 3 unchanged)
-    // halo pixel of (block row a, column l31) at tap (dy, dx): (4 wm + a + dy) * 34 + l31 + dx; its swizzle depends on l31 + dx only,
+    const int wrow = M16 ? wn * 64 + 8 * (l15 >> 2) + (l15 & 3) : wn * 64 + wl31;
+    const int wsw = ht_wkey<M16>(wrow);   // (+ 32 t, + 4 e leave the key unchanged)
+    // halo pixel of (block row a, column c) at tap (dy, dx): (4 wm + a + dy) * 34 + c + dx; its swizzle depends on c + dx only,
     // so the 3 x 2 byte offsets below plus compile-time displacements address every pixel fragment
     int poff[3][2];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) poff[dx][j] = ((4 * wm) * HT_HW + l31) * 64 + ((2 * j + kh) ^ (((l31 + dx) >> 2) & 3)) * 16;
-    tf16x8 fp[4][2], fw[2][2];
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (!M16) poff[dx][j] = ((4 * wm) * HT_HW + l31) * 64 + ((2 * j + kh) ^ ht_pkey<false>(l31 + dx)) * 16;
+            else poff[dx][j] = ((4 * wm) * HT_HW + 16 * j + l15) * 64 + (kg ^ ht_pkey<true>(16 * j + l15 + dx)) * 16;   // j = column half
+        }
+    tf16x8 fp[4][2], fw[2][2];   // 32x32x16: [a][k-half], [b][k-half]; 16x16x32: [a][column half], [t][e]
 #define HT_READ(s_, tap_)                                                                                   \
     {                                                                                                       \
         const char *img_ = tsm + (((s_) / 9) & 1) * HT_IMG;                                                 \
         const char *ws_ = wst + ((s_) & (HT_NWS - 1)) * HT_WST;                                             \
         _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                                    \
-            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                \
-                fw[b_][j_] = *reinterpret_cast<const tf16x8 *>(ws_ + ((wrow + 32 * b_) * 4 + ((2 * j_ + kh) ^ wsw)) * 16); \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                              \
+                if constexpr (!M16) fw[b_][j_] = *reinterpret_cast<const tf16x8 *>(ws_ + ((wrow + 32 * b_) * 4 + ((2 * j_ + kh) ^ wsw)) * 16); \
+                else fw[b_][j_] = *reinterpret_cast<const tf16x8 *>(ws_ + ((wrow + 32 * b_ + 4 * j_) * 4 + (kg ^ wsw)) * 16); \
+            }                                                                                               \
         _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                                    \
             _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                \
                 fp[a_][j_] = *reinterpret_cast<const tf16x8 *>(img_ + poff[(tap_) % 3][j_] + ((a_ + (tap_) / 3) * HT_HW + (tap_) % 3) * 64); \
     }
 #define HT_MFMA()                                                                                           \
     __builtin_amdgcn_s_setprio(1);                                                                          \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                        \
+    if constexpr (!M16) {                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                    \
+            _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                                \
+                _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                            \
+                    acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[b_][j_], fp[a_][j_], acc[a_][b_], 0, 0, 0); \
+    } else {                                                                                                \
         _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                                    \
-            _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                                \
-                acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[b_][j_], fp[a_][j_], acc[a_][b_], 0, 0, 0); \
+            _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                \
+                _Pragma("unroll") for (int cb_ = 0; cb_ < 4; ++cb_)                                         \
+                    acc4[a_][h_][cb_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[cb_ >> 1][cb_ & 1], fp[a_][h_], acc4[a_][h_][cb_], 0, 0, 0); \
+    }                                                                                                       \
     __builtin_amdgcn_s_setprio(0);
 #define HT_BAR()                                                                                            \
     asm volatile("s_barrier" ::: "memory");                                                                 \
@@ -211,24 +269,41 @@ __global__ __launch_bounds__(512) void conv_ht_f16(const ConvParams p) {
 #undef HT_MFMA
 #undef HT_BAR
 
-    // ---- epilogue straight from the accumulators: register 8j + u of block (a, b) = channel 32 b + 16 j + 8 kh + u of pixel (row a, column l31)
+    // ---- epilogue straight from the accumulators.  32x32x16: register 8j + u of block (a, b) = channel 32 b + 16 j + 8 kh + u of pixel
+    // (row a, column l31); 16x16x32: registers of blocks (2 t, 2 t + 1) of (a, h) = channels 32 t + 8 kg + 0 .. 7 of pixel (row a, column 16 h + l15)
     const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
     const int nb0 = nt * 128 + wn * 64;
     const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 7) & ~7);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const size_t pix = (size_t)(n * p.H + by * 16 + 4 * wm + a) * p.W + bx * 32 + l31;
-        _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + pix * p.ldc;
+        if constexpr (!M16) {
+            const size_t pix = (size_t)(n * p.H + by * 16 + 4 * wm + a) * p.W + bx * 32 + l31;
+            _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + pix * p.ldc;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = nb0 + 32 * b + 16 * j + 8 * kh;
-                tf16x8 hv;
+                for (int j = 0; j < 2; ++j) {
+                    const int col = nb0 + 32 * b + 16 * j + 8 * kh;
+                    tf16x8 hv;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + 0.f, lo);
-                if (col < cend) *reinterpret_cast<tf16x8 *>(orow + col) = hv;
+                    for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc[a][b][8 * j + u] * p.acc_scale + 0.f, lo);
+                    if (col < cend) *reinterpret_cast<tf16x8 *>(orow + col) = hv;
+                }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const size_t pix = (size_t)(n * p.H + by * 16 + 4 * wm + a) * p.W + bx * 32 + 16 * h + l15;
+                _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + pix * p.ldc;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int col = nb0 + 32 * t + 8 * kg;
+                    tf16x8 hv;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc4[a][h][2 * t + (u >> 2)][u & 3] * p.acc_scale + 0.f, lo);
+                    if (col < cend) *reinterpret_cast<tf16x8 *>(orow + col) = hv;
+                }
             }
+        }
     }
     if (p.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -241,6 +316,11 @@ __global__ __launch_bounds__(512) void conv_ht_f16(const ConvParams p) {
 static int g_ht_mode = -1;   // -1: launch_conv's rule (enough tiles to fill the chip); 0 never, 1 always (op-level tests)
 void conv_ht_set_mode(int mode) { g_ht_mode = mode; }
 int conv_ht_mode() { return g_ht_mode; }
+// MFMA shape of the tall-tile layers: 1 = 16x16x32 (the engine's: 12-15 % less time, profiles/r04_probe_mfma_shape.txt), 0 = 32x32x16 (the
+// A/B partner, hmv_op_conv2d_f16 kernel_sel 5 / 6).  A property of the BUILD, not of a launch: every batch size runs the same shape.
+static int g_ht_m16 = 1;
+void conv_ht_set_shape(int m16) { g_ht_m16 = m16; }
+int conv_ht_shape() { return g_ht_m16; }
 
 // shape rule (the engine asks it at weight-packing time and at launch: the same answer for every batch)
 bool conv_ht_shape_ok(int R, int S, int stride, int pad, int Cin, int Cout, int H, int W) {
@@ -259,14 +339,20 @@ hipError_t launch_conv_ht(ConvParams p, hipStream_t s, const char **name) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_ht_f16), hipFuncAttributeMaxDynamicSharedMemorySize, HT_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_ht_f16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HT_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_ht_f16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, HT_LDS);
         if (e != hipSuccess) return e;
         configured[dev] = true;
     }
     p.mtiles = p.N * (p.H >> 4) * (p.W >> 5);
     p.ntiles = p.Cout / 128;
+    if (g_ht_m16) {
+        if (name) *name = "conv_ht_f16<512x128,3x3,m16>";
+        hipLaunchKernelGGL(conv_ht_f16<true>, dim3(p.mtiles * p.ntiles), dim3(512), HT_LDS, s, p);
+        return hipGetLastError();
+    }
     if (name) *name = "conv_ht_f16<512x128,3x3>";
-    hipLaunchKernelGGL(conv_ht_f16, dim3(p.mtiles * p.ntiles), dim3(512), HT_LDS, s, p);
+    hipLaunchKernelGGL(conv_ht_f16<false>, dim3(p.mtiles * p.ntiles), dim3(512), HT_LDS, s, p);
     return hipGetLastError();
 }
 

@@ -1365,12 +1365,21 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
         if (ht_min < 0) { const char *e = HMV_DEV_ENV("HMV_HT_MIN_TILES"); ht_min = e ? atoi(e) : 256; }
         const long long ht_tiles = (long long)p.N * (p.H >> 4) * (p.W >> 5) * (p.Cout / 128);
         if (conv_ht_mode() > 0 || (conv_ht_mode() < 0 && ht_tiles >= ht_min)) return launch_conv_ht(p, s, name);
+        // small launches: conv_m16.hip's 64 x 64 / 128 x 128 tiles on the same 16x16x32 MFMA (same bits as conv_ht<..., m16>); the c32
+        // instantiations below are the 32x32x16 partner of the shape A/B (conv_ht_set_shape(0), op-level tests only)
+        if (conv_ht_shape()) return launch_conv_m16(p, s, name);
         if ((long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) < 256) {
             if (name) *name = "conv_igemm_f16<64x64,taps,c32>";
             return launch_one<_Float16, 64, 64, 2, 2, MODE_TAPS, false, 32, false, false, false, true>(p, s);
         }
         if (name) *name = "conv_igemm_f16<128x128,taps,c32>";
         return launch_one<_Float16, 128, 128, 2, 2, MODE_TAPS, false, 32, false, false, false, true>(p, s);
+    }
+    // MFMA-heavy fp16 1x1 convs without a residual (layer3's conv1, pose_net.0): the 16x16x32 MFMA at EVERY batch size -- the
+    // phase-interleaved 256 x 256 tile where its tiles fill the chip, conv_m16.hip's small tiles elsewhere (same bits)
+    if (!generic && conv_m16_rule(p)) {
+        p.m16 = 1;
+        return conv_gemm8_supported(p) ? launch_conv_gemm8(p, s, name) : launch_conv_m16(p, s, name);
     }
     // short-reduction residual 1x1 convs over many pixels (fp16 Bottleneck conv3): the persistent weight-stationary kernel
     if (!generic && conv_stream_supported(p)) return launch_conv_stream(p, s, name);

@@ -2316,15 +2316,17 @@ extern "C" int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int
                                  const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad,
                                  const float *residual, int32_t relu, void *out_f16, int32_t kernel_sel, const char **kernel_name,
                                  void *stream) {
-    if (kernel_sel < 0 || kernel_sel > 4) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0 .. 4"; return HMV_ERR_ARG; }
-    const int force = kernel_sel == 0 ? -1 : (kernel_sel == 2 ? 1 : 0);   // 3 / 4 (tall-tile packing) keep the other special kernels out
-    conv_ht_set_mode(kernel_sel == 3 ? 1 : (kernel_sel == 4 ? 0 : -1));
+    if (kernel_sel < 0 || kernel_sel > 6) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0 .. 6"; return HMV_ERR_ARG; }
+    const int force = kernel_sel == 0 ? -1 : (kernel_sel == 2 ? 1 : 0);   // 3 .. 6 (tall-tile packing) keep the other special kernels out
+    conv_ht_set_mode((kernel_sel == 3 || kernel_sel == 5) ? 1 : ((kernel_sel == 4 || kernel_sel == 6) ? 0 : -1));
+    conv_ht_set_shape(kernel_sel >= 5 ? 0 : 1);
     conv_stream_set_mode(force);
     conv_gemm8_set_mode(force);
     conv_hs_set_mode(force);
     const int rc = op_conv2d_any("hmv_op_conv2d_f16", device, HMV_F16, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad,
-                                 residual, relu, out_f16, true, kernel_name, stream, kernel_sel >= 3);
+                                 residual, relu, out_f16, true, kernel_name, stream, kernel_sel >= 3);   // (3 .. 6: the tall-tile packing)
     conv_ht_set_mode(-1);
+    conv_ht_set_shape(1);
     conv_stream_set_mode(-1);
     conv_gemm8_set_mode(-1);
     conv_hs_set_mode(-1);

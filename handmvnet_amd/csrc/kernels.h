@@ -56,6 +56,7 @@ struct ConvParams {
     int acc_shift;      // split layers: the packed weights are W * 2^acc_shift (keeps W_lo out of the fp16 subnormals);
     float acc_scale;    //   the epilogue multiplies the accumulator by 2^-acc_shift (filled in by launch_conv)
     int out_split;      // write (hi, lo) pairs (plane stride ldc / 2) instead of one fp16 value
+    int m16;            // fp16 1x1 that multiplies on v_mfma_f32_16x16x32_f16 at every batch size (filled in by launch_conv from conv_m16_rule)
     int tall;           // fp16 3x3 whose weights are packed in conv_ht.hip's K order: that kernel or an error, at every batch size
     int rd_cout;        // row-decomposed 3x3 (narrow Cout): the real channel count; Cout is then 3 * rd_cout, R = 3, S = 1
     // second A source of a plain 1x1 conv (Bottleneck conv3 and its block's downsample conv as ONE GEMM over the concatenated
@@ -190,6 +191,16 @@ bool conv_ht_shape_ok(int R, int S, int stride, int pad, int Cin, int Cout, int 
 hipError_t launch_conv_ht(ConvParams p, hipStream_t s, const char **name);
 void conv_ht_set_mode(int mode);   // -1 launch_conv's rule, 0 never (the c32 tiles of conv_igemm.hip), 1 always: op-level tests
 int conv_ht_mode();
+void conv_ht_set_shape(int m16);   // MFMA shape of the tall-tile layers: 1 = 16x16x32 (the engine's, round 4), 0 = 32x32x16 (the A/B partner)
+int conv_ht_shape();
+// conv_m16.hip: the small-launch companion of the 16x16x32-MFMA kernels (64 x 64 / 128 x 128 tiles; 3x3 in conv_ht's K order, plain
+// 1x1): same bits as conv_ht<..., m16>, so a layer's result does not depend on which of the two its batch size selects
+bool conv_m16_supported(const ConvParams &p);
+// the plain 1x1 layers that take the 16x16x32 MFMA: a rule on the layer's SHAPE and epilogue only (never on M), so that the large
+// launches (conv_gemm8<..., m16>) and the small ones (conv_m16's tiles) of one layer agree bit for bit
+bool conv_m16_rule(const ConvParams &p);
+void conv_m16_set_rule(int on);   // 1 (default) / 0: op-level A/B against the 32x32x16 kernels
+hipError_t launch_conv_m16(ConvParams p, hipStream_t s, const char **name);
 
 // ---- fusion_kernels.hip: the launch-bound tail as fused kernels
 // Everything of a fusion block behind its to_out GEMM (layers.py:224-233 / 161-174; learnable-query blocks: layers.py:293-299):

@@ -193,9 +193,14 @@ int hmv_op_conv2d_sel(int32_t device, const float *in, int32_t N, int32_t H, int
  * weight-stationary residual 1x1; conv_gemm8.hip: phase-interleaved 256 x 256 1x1; conv_hs.hip: halo-streaming few-channel 3x3)
  * wherever the shape has one, whatever its size; 3 = the tall-tile 3x3 kernel (conv_ht.hip: 3x3 stride 1 pad 1 without residual,
  * Cin % 32 == 0 >= 64, Cout % 128 == 0, H % 16 == 0, W % 32 == 0, else HMV_ERR_ARG) with the weights packed in ITS reduction order,
- * as hmv_finalize_weights packs the layers the engine gives to it; 4 = the same packing on conv_igemm's 32-channel-chunk tiles
- * (what such a layer runs on when the batch is too small for 512-pixel tiles: same bits as 3).  *kernel_name (optional)
- * receives the family that ran. */
+ * as hmv_finalize_weights packs the layers the engine gives to it, on the 16x16x32 fp16 MFMA (the engine's shape since round 4);
+ * 4 = the same packing on the small-launch tiles (conv_m16.hip: what such a layer runs on when the batch is too small for
+ * 512-pixel tiles: same bits as 3); 5 / 6 = as 3 / 4 on the 32x32x16 fp16 MFMA (conv_ht's other instantiation / conv_igemm's
+ * 32-channel-chunk tiles: the partner of the MFMA-shape A/B of round 4, not used by the engine; 5 and 6 agree bit for bit with
+ * each other, and with 3 / 4 to the last fp16 bit of a few outputs).  *kernel_name (optional) receives the family that ran.
+ * TEST HOOKS: the hmv_op_* entries with a kernel_sel argument switch PROCESS-GLOBAL kernel-selection state for the duration of the
+ * call.  They are single-threaded test / probe entries: never call one concurrently with any other hmv_* call of the process
+ * (an hmv_forward running on another thread would see the forced selection). */
 int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t Cin,
                       const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride,
                       int32_t pad, const float *residual, int32_t relu, void *out_f16, int32_t kernel_sel,

@@ -143,7 +143,12 @@ def run_case(name: str, spec: dict, check_oracle: bool = True) -> dict:
         fx["tokens_full"] = stages["tokens"].numpy().copy()
         fx["amp_fused"] = np.float64(max(amp_f))
         fx["amp_joints_cam"] = np.float64(max(amp_c))
-        print(f"  conditioning: d(fused)/d(tokens) up to {fx['amp_fused']:.0f}, d(joints_cam)/d(tokens) up to {fx['amp_joints_cam']:.0f}; "
+        # the typical (median over the eight draws) amplification beside the worst one: an implementation's own token error reaches
+        # the pose through some direction, not the worst; the end-to-end allowance of the tests is
+        # cap x cond_*32_vs_64 (the tail itself) + 2 x typical amplification x token error, never above 2 x worst x token error
+        fx["amp_fused_med"] = np.float64(np.median(amp_f))
+        fx["amp_joints_cam_med"] = np.float64(np.median(amp_c))
+        print(f"  conditioning: d(fused)/d(tokens) up to {fx['amp_fused']:.0f} (median {fx['amp_fused_med']:.0f}), d(joints_cam)/d(tokens) up to {fx['amp_joints_cam']:.0f} (median {fx['amp_joints_cam_med']:.0f}); "
               f"reference fp32 fused vs its float64 fusion {fx['cond_fused32_vs_64']:.3e}, joints_cam {fx['cond_joints_cam32_vs_64']:.3e}")
     if check_oracle:
         from oracle.oracle import Oracle

@@ -33,6 +33,10 @@ from ref_harness import build_reference_model  # noqa: E402
 from cases import CASES as _ALL  # noqa: E402
 
 CASES = list(_ALL)
+# joints_cam of the fp16-storage run is dominated by WHICH near-tied heat-map peaks flip (soft-argmax x 1000) and by how the random-weight
+# fusion amplifies those few token rows: one sample is one draw of a heavy-tailed quantity.  For these cases the floor is measured on
+# several samples drawn from the same input distribution (same weights; sample 0 = the fixture's sample) and the per-sample list kept.
+NOISE_SAMPLES = {"hr40_v8_256": 6}
 
 
 
@@ -48,8 +52,12 @@ def round_out(_m, _i, o):
     return r16(o)
 
 
-def run(name, rounded):
+def run(name, rounded, batch=None):
     cfg, (tp, mp, dp), sd, (x, bbox, intr), fx = load_case(name)
+    if batch:
+        from cases import CASES as _C
+        from handmvnet_amd.synth import synth_inputs
+        x, bbox, intr = synth_inputs(cfg, batch, _C[name]["iseed"], _C[name]["size"])   # sample 0 = the fixture's sample (counter hash)
     model = build_reference_model(tp, mp, dp, sd)
     hooks = []
     if rounded:
@@ -95,6 +103,12 @@ def main():
         dc = np.abs(got["joints_crop_img"] - ref["joints_crop_img"]) * k
         res[name] = {"heatmap_rel_l2": rel(got["heatmap"], ref["heatmap"]), "coord_median_px": float(np.median(dc)),
                      "coord_flip_frac": float((dc > 0.5).mean()), "joints_cam_rel_l2": rel(got["joints_cam"], ref["joints_cam"])}
+        if name in NOISE_SAMPLES:
+            _, refb = run(name, False, NOISE_SAMPLES[name])
+            _, gotb = run(name, True, NOISE_SAMPLES[name])
+            res[name]["joints_cam_rel_l2_samples"] = [rel(gotb["joints_cam"][i], refb["joints_cam"][i]) for i in range(NOISE_SAMPLES[name])]
+            res[name]["heatmap_rel_l2_samples"] = [rel(gotb["heatmap"][i], refb["heatmap"][i]) for i in range(NOISE_SAMPLES[name])]
+            assert abs(res[name]["joints_cam_rel_l2_samples"][0] - res[name]["joints_cam_rel_l2"]) < 1e-9
         print(name, res[name], flush=True)
     with open(os.path.join(HERE, "fp16_noise.json"), "w") as f:
         json.dump({"what": "deviation of the reference run with fp16-storage roundings from the unrounded reference "

@@ -34,18 +34,23 @@ def load_case(name: str):
 def cond_bounds(fx: dict, tol_cam: float, tol_fused, tok_err: float = None, cond_cap: float = 4.0):
     """Tolerances behind the token matrix for fixtures of ill-conditioned configurations (make_fixtures.py, `cond`).
 
-    Such a fixture carries (a) the worst-case amplification of a token perturbation measured on the reference's own fusion module in
-    float64 (`amp_*`: 10^2 .. 10^3 for un-normalised learnable-query blocks on HRNet features) and (b) how far the REFERENCE's own
-    fp32 run sits from its float64 fusion -> decoder on the same tokens (`cond_*32_vs_64`).  The allowance is
-    min(2 x amp x the implementation's own token error, cond_cap x cond_*32_vs_64), never below the fixed bar: the amplification
-    alone would admit errors three orders of magnitude above what fp32 really does there."""
+    Such a fixture carries (a) the amplification of a relative token perturbation into `fused` / joints_cam measured on the
+    reference's own fusion module in float64 -- worst and median of eight draws (`amp_*`, `amp_*_med`: up to 6 000 / typically
+    1 200 for un-normalised learnable-query blocks on HRNet features) -- and (b) how far the REFERENCE's own fp32 run sits from its
+    float64 fusion -> decoder on the same tokens (`cond_*32_vs_64`).
+
+    * tok_err None (the tail alone, run on given tokens): cond_cap x cond_*32_vs_64, never below the fixed bar.
+    * tok_err given (end to end: the implementation's own token error travels through the tail as well):
+      cond_cap x cond_*32_vs_64 + median amplification x token error, never above 2 x worst amplification x token error and
+      never below the fixed bar.  (Round 3 allowed the worst-case term alone: 1e-2 .. 1 where fp32 really does 3e-4)"""
     if "amp_fused" not in fx:
         return tol_cam, tol_fused
     out = []
-    for fixed, amp, cond in ((tol_cam, "amp_joints_cam", "cond_joints_cam32_vs_64"), (tol_fused or 0.0, "amp_fused", "cond_fused32_vs_64")):
-        allow = cond_cap * float(fx[cond])
+    for fixed, nm in ((tol_cam, "joints_cam"), (tol_fused or 0.0, "fused")):
+        allow = cond_cap * float(fx[f"cond_{nm}32_vs_64"])
         if tok_err is not None:
-            allow = min(allow, 2.0 * float(fx[amp]) * max(tok_err, 1e-6))
+            t = max(tok_err, 1e-6)
+            allow = min(2.0 * float(fx[f"amp_{nm}"]) * t, allow + float(fx[f"amp_{nm}_med"]) * t)
         out.append(max(fixed, allow))
     return out[0], out[1]
 

@@ -53,7 +53,6 @@ typedef _Float16 gf16x8 __attribute__((ext_vector_type(8)));
 // DUAL: the reduction is the concatenation [first source | second source] (conv3 + downsample as one GEMM, ConvParams::in2)
 template <bool DUAL, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void conv_gemm8_f16(const ConvParams p) {
-    static_assert(!(DUAL && M16), "the 16x16x32 form is built for single-source launches");
     constexpr int HT = 128 * 64;   // halfs per half-tile
     extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];   // [2 k-steps][A0, A1, B0, B1][128][64]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -520,14 +519,16 @@ hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8_f16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8_f16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8_f16<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8_f16<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured[dev] = true;
     }
     p.mtiles = (p.M + 255) / 256;
     p.ntiles = (p.Cout + 255) / 256;
-    if (p.m16 && !p.in2) {   // the layer multiplies on the 16x16x32 MFMA at every batch size (conv_m16_rule: by shape)
-        if (name) *name = "conv_gemm8_f16<256x256,1x1,m16>";
-        hipLaunchKernelGGL((conv_gemm8_f16<false, true>), dim3(p.mtiles * p.ntiles), dim3(512), lds, s, p);
+    if (p.m16) {   // the layer multiplies on the 16x16x32 MFMA at every batch size (conv_m16_rule: by shape)
+        if (name) *name = p.in2 ? "conv_gemm8_f16<256x256,1x1,dual,m16>" : "conv_gemm8_f16<256x256,1x1,m16>";
+        if (p.in2) hipLaunchKernelGGL((conv_gemm8_f16<true, true>), dim3(p.mtiles * p.ntiles), dim3(512), lds, s, p);
+        else hipLaunchKernelGGL((conv_gemm8_f16<false, true>), dim3(p.mtiles * p.ntiles), dim3(512), lds, s, p);
         return hipGetLastError();
     }
     if (name) *name = p.in2 ? "conv_gemm8_f16<256x256,1x1,dual>" : "conv_gemm8_f16<256x256,1x1>";

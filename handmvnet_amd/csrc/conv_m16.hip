@@ -34,9 +34,11 @@ constexpr int M16_NS = 4;   // LDS stages (tiles kt .. kt + 3)
 // of k-group g ^ 1, and this key puts the 16 on distinct bank quads (tools/probe/swizzle_search.py).
 __device__ __forceinline__ int m16_key(int row) { return ((row >> 2) & 1) << 1; }
 
-// TAPS: 3x3 stride 1 pad 1 in conv_ht's K order; else a plain 1x1 (stride 1) over rows of lda halfs
-template <int BM, int BN, bool TAPS>
+// TAPS: 3x3 stride 1 pad 1 in conv_ht's K order; else a plain 1x1 (stride 1) over rows of lda halfs.  DUAL (1x1 only): the reduction is
+// the concatenation [first source | second source sampled at (ho, wo) * stride2] (conv3 + downsample as one GEMM, ConvParams::in2)
+template <int BM, int BN, bool TAPS, bool DUAL = false>
 __global__ __launch_bounds__(256) void conv_m16_f16(const ConvParams p) {
+    static_assert(!(TAPS && DUAL), "two sources: 1x1 only");
     constexpr int WM = BM / 2, WN = BN / 2, PB = WM / 16, CB = WN / 16, AP = BM / 64, BP = BN / 64;
     static_assert(CB % 2 == 0, "a lane's channel blocks pair up into 8 consecutive channels");
     extern __shared__ __attribute__((aligned(16))) char msm[];   // [M16_NS][BM + BN][64 bytes]
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void conv_m16_f16(const ConvParams p) {
 
     // ---- DMA roles: thread -> row tid >> 2 of each 64-row pass, physical chunk tid & 3 holding logical chunk (tid & 3) ^ key(row)
     const int lrow = tid >> 2, lc = (tid & 3) ^ m16_key(lrow);
-    const _Float16 *aptr[AP];
+    const _Float16 *aptr[AP], *aptr2[AP];
     int hi0[AP], wi0[AP];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -74,6 +76,13 @@ __global__ __launch_bounds__(256) void conv_m16_f16(const ConvParams p) {
         } else {
             hi0[i] = wi0[i] = 0;
             aptr[i] = ok ? reinterpret_cast<const _Float16 *>(p.in) + (size_t)mm * p.lda + 8 * lc : nullptr;
+        }
+        aptr2[i] = nullptr;
+        if constexpr (DUAL) {
+            if (ok) {
+                const int n = mm / HoWo, rem = mm - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                aptr2[i] = reinterpret_cast<const _Float16 *>(p.in2) + ((size_t)(n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.lda2 + 8 * lc;
+            }
         }
     }
     // weight LDS row R = 32 u + 16 e + rho holds channel 32 u + 8 (rho >> 2) + 4 e + (rho & 3): block pair (2 t, 2 t + 1) of a lane then
@@ -95,6 +104,9 @@ __global__ __launch_bounds__(256) void conv_m16_f16(const ConvParams p) {
             if constexpr (TAPS) {
                 const bool ok = live && (unsigned)(hi0[i] + cr) < (unsigned)p.H && (unsigned)(wi0[i] + cs) < (unsigned)p.W;
                 src = ok ? aptr[i] + ((size_t)cr * p.W + cs) * p.lda + 32 * cchunk : zero16;
+            } else if constexpr (DUAL) {
+                const int k0 = 32 * ck;
+                src = (live && aptr[i]) ? (k0 < p.ksplit ? aptr[i] + k0 : aptr2[i] + (k0 - p.ksplit)) : zero16;
             } else {
                 src = (live && aptr[i]) ? aptr[i] + 32 * ck : zero16;
             }
@@ -197,10 +209,15 @@ __global__ __launch_bounds__(256) void conv_m16_f16(const ConvParams p) {
 
 // ====================================================================== host side
 bool conv_m16_supported(const ConvParams &p) {
-    if (!p.in_f16 || !p.out_f16 || p.res || p.in2 || p.up || p.ksl > 1 || p.phases > 1 || p.cwrap || p.x3_plane || p.out_split || p.acc_shift ||
+    if (!p.in_f16 || !p.out_f16 || p.res || p.up || p.ksl > 1 || p.phases > 1 || p.cwrap || p.x3_plane || p.out_split || p.acc_shift ||
         p.rd_cout || p.scatter || p.rg_out || p.nx_wgt || p.pool || (p.act != ACT_NONE && p.act != ACT_RELU))
         return false;
     const int lda = p.lda ? p.lda : p.Cin, ldw = p.ldw ? p.ldw : p.Kpad;
+    if (p.in2) {   // [t2 | x]: whole 32-channel steps on either side of the seam, every reduction column a real channel of its source
+        return p.R == 1 && p.S == 1 && p.stride == 1 && !p.pad_h && !p.pad_w && p.K == p.Kpad && p.Kpad % 32 == 0 && p.ksplit > 0 &&
+               p.ksplit < p.Kpad && p.ksplit % 32 == 0 && lda >= p.ksplit && p.lda2 >= p.Kpad - p.ksplit && !(lda & 7) && !(p.lda2 & 7) &&
+               !(ldw & 7) && !(p.ldc & 7) && p.Cout % 64 == 0 && p.stride2 >= 1;
+    }
     if ((lda & 7) || (ldw & 7) || (p.ldc & 7) || p.Cin % 32 || p.Cout % 64 || lda < p.Cin) return false;
     if ((long long)p.N * p.H * p.W * lda >= (1ll << 31)) return false;
     if (p.R == 3 && p.S == 3) return p.stride == 1 && p.pad_h == 1 && p.pad_w == 1 && p.Ho == p.H && p.Wo == p.W && p.Kpad >= 9 * p.Cin;
@@ -213,23 +230,25 @@ bool conv_m16_supported(const ConvParams &p) {
 static int g_m16_rule = 1;
 void conv_m16_set_rule(int on) { g_m16_rule = on; }
 bool conv_m16_rule(const ConvParams &p) {
-    return g_m16_rule && conv_m16_supported(p) && p.R == 1 && p.Kpad % 64 == 0 && p.Kpad >= 128 && p.Cout > 128 && !p.tall && !p.fill;
+    // (two-source launches: only the long one, layer3.0's conv3 + downsample, K = 256 + 512; the K = 128 / 384 ones of layer1.0 / layer2.0
+    // are HBM-bound and belong to conv_stream.hip at every size that matters)
+    return g_m16_rule && conv_m16_supported(p) && p.R == 1 && p.Kpad % 64 == 0 && p.Kpad >= (p.in2 ? 768 : 128) && p.Cout > 128 && !p.tall && !p.fill;
 }
 
-template <int BM, int BN, bool TAPS>
+template <int BM, int BN, bool TAPS, bool DUAL = false>
 static hipError_t launch_m16(ConvParams p, hipStream_t s) {
     constexpr int lds = M16_NS * (BM + BN) * 64;
     static bool configured[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!configured[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_m16_f16<BM, BN, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_m16_f16<BM, BN, TAPS, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         configured[dev] = true;
     }
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = p.Cout / BN;
-    hipLaunchKernelGGL((conv_m16_f16<BM, BN, TAPS>), dim3(p.mtiles * p.ntiles), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_m16_f16<BM, BN, TAPS, DUAL>), dim3(p.mtiles * p.ntiles), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -240,6 +259,10 @@ hipError_t launch_conv_m16(ConvParams p, hipStream_t s, const char **name) {
     const bool taps = p.R == 3;
     // 64 x 64 tiles while 128 x 128 ones would leave CUs idle (the rule of conv_igemm's small-launch tiles)
     const bool small = p.Cout % 128 != 0 || (long long)((p.M + 127) / 128) * (p.Cout / 128) < 256;
+    if (p.in2) {
+        if (name) *name = small ? "conv_m16_f16<64x64,1x1,dual>" : "conv_m16_f16<128x128,1x1,dual>";
+        return small ? launch_m16<64, 64, false, true>(p, s) : launch_m16<128, 128, false, true>(p, s);
+    }
     if (small) {
         if (name) *name = taps ? "conv_m16_f16<64x64,taps,c32>" : "conv_m16_f16<64x64,1x1>";
         return taps ? launch_m16<64, 64, true>(p, s) : launch_m16<64, 64, false>(p, s);

@@ -1240,7 +1240,7 @@ struct Runner {
     }
     void ff_block(const Layer &out, const Layer &ff1, const Layer &ff2, const float *att, int rows, const float *res, int ldr, int rg_out,
                   int rg_in, const float *n1g, const float *n1b, const float *fg, const float *fb, const float *n2g, const float *n2b,
-                  float *y, int ldt, int d) {
+                  float *y, int ldt, int d, float *y_pairs = nullptr) {
         const int S = splitk_slices(out, rows), lds_ = (out.Cout + 3) / 4 * 4;
         float *slab = alloc((size_t)S * rows * lds_);
         Layer Ls = out;
@@ -1255,7 +1255,7 @@ struct Runner {
             p.rows = rows; p.d = d; p.ld = ldt;
             p.n1g = n1g; p.n1b = n1b; p.fg = fg; p.fb = fb; p.n2g = n2g; p.n2b = n2b;
             p.w1 = ff1.w; p.b1 = ff1.bias; p.ldw1 = ff1.Kpad; p.w2 = ff2.w; p.b2 = ff2.bias; p.ldw2 = ff2.Kpad;
-            p.out = y; p.ldo = ldt; p.hid = ff1.Cout;
+            p.out = y; p.ldo = ldt; p.hid = ff1.Cout; p.out_pairs = y_pairs;
 #ifdef HMV_DEV_KNOBS
             static unsigned long long *ffdbg = nullptr;   // HMV_FF_DBG=1: phase stamps of the last launch, printed by the next one (never under graph capture)
             if (HMV_DEV_ENV("HMV_FF_DBG")) {
@@ -1670,19 +1670,26 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         col0 += co;
     }
     for (int i = 0; i < nkeep; ++i) R.release(lvl[i]);
-    // pos2d / FoV / zero pad / PE (handmvnet.py:189-225; fusion.py:27-28)
+    // pos2d / FoV / zero pad / PE (handmvnet.py:189-225; fusion.py:27-28).  In the fp16-kernel modes the q/k/v projections of
+    // CrossAttentionFusion read their token rows as (hi, lo) fp16 pairs: the kernel that produces a block's input rows -- this one for
+    // block 0, ff_block_kernel for the others -- writes that copy itself (rows_f32_to_half's arithmetic, one launch less per block)
+    float *Xpairs = nullptr;   // [hi ldt | lo ldt] halfs per row of X, when its producer wrote them
+    if (!h->lq && c.fusion_layers > 0 && h->attn[0].qkv.plane) Xpairs = R.alloc((size_t)N * NJ * ldt);
     LAUNCH(launch_tokens_finalize(tokens, ldt, d, h->fdim, N, V, coords, bbox, intr, c.pos_enc,
                                   (h->lq || !(c.pos_enc & HMV_POS_SIN)) ? nullptr : h->pe,   // the learnable-query blocks add their own PE
-                                  (h->capture && h->cap_tokens) ? h->cap_tokens : nullptr, s));
+                                  (h->capture && h->cap_tokens) ? h->cap_tokens : nullptr, s, Xpairs));
     R.release(coords);
 
     float *X = tokens;
     int Tcur = V * NJ;
     // q/k/v projection of fp32 token rows; in the fp16 / f32x3 modes on the fused split kernels (Loader::linear_x3)
-    auto project = [&](const Layer &L, const float *a, int rows, float *out, int ldc) {
+    auto project = [&](const Layer &L, const float *a, int rows, float *out, int ldc, float *ready_pairs = nullptr) {
         if (!L.plane) { R.gemm(L, a, rows, out, ldc, nullptr, 0, ACT_NONE); return; }
-        float *pairs = R.alloc((size_t)rows * ldt);                        // [hi ldt | lo ldt] halfs per row
-        LAUNCH(launch_rows_f32_to_half(a, pairs, (size_t)rows, ldt, 2, s));
+        float *pairs = ready_pairs;
+        if (!pairs) {
+            pairs = R.alloc((size_t)rows * ldt);                           // [hi ldt | lo ldt] halfs per row
+            LAUNCH(launch_rows_f32_to_half(a, pairs, (size_t)rows, ldt, 2, s));
+        }
         R.conv(L, pairs, rows, 1, 1, 1, 0, 0, out, ldc, nullptr, 0, ACT_NONE, 1, 1);
         R.release(pairs);
     };
@@ -1749,15 +1756,17 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         const int Tq = cross ? NJ : Tcur, koff = cross ? NJ : 0, Tk = cross ? Tcur - NJ : Tcur;
         const int rows = B * Tcur, qrows = B * Tq;
         float *qkv = R.alloc((size_t)rows * 3 * INNER);
-        project(a.qkv, X, rows, qkv, 3 * INNER);
+        project(a.qkv, X, rows, qkv, 3 * INNER, Xpairs);
+        Xpairs = nullptr;
         float *att = R.alloc((size_t)qrows * INNER);
         if (Tk > 0) LAUNCH(launch_attention(qkv, B, Tcur, Tq, koff, Tk, att, s));
         else LAUNCH(hipMemsetAsync(att, 0, (size_t)qrows * INNER * sizeof(float), s));
         R.release(qkv);
         if (R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt)) {   // norm1(to_out + _q) -> FeedForward -> norm2 in one launch behind the GEMM
             float *Xf = R.alloc((size_t)qrows * ldt);
+            if (l + 1 < c.fusion_layers && h->attn[l + 1].qkv.plane) Xpairs = R.alloc((size_t)qrows * ldt);   // the next block's projection input
             R.ff_block(a.out, a.ff1, a.ff2, att, qrows, X, ldt, cross ? Tq : 0, cross ? Tcur : 0, a.n1g, a.n1b, a.fg, a.fb, a.n2g, a.n2b, Xf,
-                       ldt, d);
+                       ldt, d, Xpairs);
             R.release(att);
             R.release(X);
             X = Xf;

@@ -24,6 +24,7 @@
 namespace hmv {
 
 typedef float ff32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ff16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float fwave_sum(float v) {
 #pragma unroll
@@ -278,7 +279,21 @@ __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockPa
 #pragma unroll
             for (int i = 0; i < FF_VEC; ++i) {
                 const int c = 4 * lane + 256 * i;
-                if (row < p.rows && c < p.ldo) *reinterpret_cast<ff32x4 *>(p.out + (size_t)row * p.ldo + c) = v[r][i];
+                if (row < p.rows && c < p.ldo) {
+                    *reinterpret_cast<ff32x4 *>(p.out + (size_t)row * p.ldo + c) = v[r][i];
+                    if (p.out_pairs) {   // hi = fp16(clamp(v)), lo = fp16(clamp(v) - hi): split_f16 of misc_kernels.hip
+                        ff16x4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float cv = fminf(fmaxf(v[r][i][e], -65504.f), 65504.f);
+                            hi[e] = (_Float16)cv;
+                            lo[e] = (_Float16)(cv - (float)hi[e]);
+                        }
+                        _Float16 *pr = reinterpret_cast<_Float16 *>(p.out_pairs) + (size_t)row * 2 * p.ldo + c;
+                        *reinterpret_cast<ff16x4 *>(pr) = hi;
+                        *reinterpret_cast<ff16x4 *>(pr + p.ldo) = lo;
+                    }
+                }
             }
         }
     }

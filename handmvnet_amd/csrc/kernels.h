@@ -147,7 +147,7 @@ hipError_t launch_sample_blend(const float *s4, int lds4, int C, int N, int H, i
 // pos2d / FoV columns, zero padding columns; optional raw copy (before PE) and PE add
 hipError_t launch_tokens_finalize(float *tokens, int ldt, int d, int fdim, int N, int V, const float *coords,
                                   const float *bbox, const float *intr, int pos_mask, const float *pe,
-                                  float *raw_copy, hipStream_t s);
+                                  float *raw_copy, hipStream_t s, void *pairs = nullptr);   // pairs: rows again as [hi ldt | lo ldt] halfs
 // y = LN(x) ; optional second LN applied to y -> y2.  Pads [d, ld) are written as zeros.
 hipError_t launch_layernorm(const float *x, int ldx, int rows, int d, const float *g1, const float *b1, float *y,
                             int ldy, const float *g2, const float *b2, float *y2, hipStream_t s);
@@ -215,6 +215,8 @@ struct FfBlockParams {
     const float *w2, *b2; int ldw2;        // [>= ld rows][ldw2 >= hid]
     const float *n2g, *n2b;
     float *out; int ldo;
+    void *out_pairs;                       // optional: the output rows once more as (hi, lo) fp16 pairs [row][hi ldo | lo ldo] (the next
+                                           // block's q/k/v projection reads them in the fp16-kernel modes: rows_f32_to_half's arithmetic)
     int hid;                               // 128 | 256
     unsigned long long *dbg;               // diagnostic builds only: 100 MHz stamps at the phase boundaries of workgroup 0
 };

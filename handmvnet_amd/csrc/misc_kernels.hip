@@ -527,9 +527,11 @@ hipError_t launch_sample_blend(const float *s4, int lds4, int C, int N, int H, i
 // ------------------------------------------------------------------ token tail
 // pos2d (handmvnet.py:189-191), crop FoV (handmvnet.py:205-222, utils.py:134-171), zero pad,
 // optional capture of the raw tokens, then + sinusoidal PE (layers.py:152-158; table built on host).
+// pairs (optional): the finished rows once more as (hi, lo) fp16 pairs [row][hi ldt | lo ldt] -- what the first fusion block's q/k/v
+// projection reads in the fp16-kernel modes (rows_f32_to_half_kernel's arithmetic: same bits, one launch less)
 __global__ void tokens_finalize_kernel(float *tokens, int ldt, int d, int fdim, int V, const float *coords,
                                        const float *bbox, const float *intr, int pos_mask, const float *pe,
-                                       float *raw_copy) {
+                                       float *raw_copy, _Float16 *pairs) {
     const int row = blockIdx.x;           // n*21 + j, n = b*V + v
     const int n = row / 21, j = row - n * 21;
     float *t = tokens + (size_t)row * ldt;
@@ -553,16 +555,24 @@ __global__ void tokens_finalize_kernel(float *tokens, int ldt, int d, int fdim, 
     __syncthreads();
     const int pos = (n % V) * 21 + j;  // token index inside its sample, view-major
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
-        const float v = t[c];
+        float v = t[c];
         if (raw_copy) raw_copy[(size_t)row * d + c] = v;
-        if (pe) t[c] = v + pe[(size_t)pos * d + c];
+        if (pe) { v = v + pe[(size_t)pos * d + c]; t[c] = v; }
+        if (pairs) {
+            _Float16 a, b;
+            split_f16(v, a, b);
+            pairs[(size_t)row * 2 * ldt + c] = a;
+            pairs[(size_t)row * 2 * ldt + ldt + c] = b;
+        }
     }
+    if (pairs)
+        for (int c = d + threadIdx.x; c < ldt; c += blockDim.x) { pairs[(size_t)row * 2 * ldt + c] = (_Float16)0.f; pairs[(size_t)row * 2 * ldt + ldt + c] = (_Float16)0.f; }
 }
 hipError_t launch_tokens_finalize(float *tokens, int ldt, int d, int fdim, int N, int V, const float *coords,
                                   const float *bbox, const float *intr, int pos_mask, const float *pe, float *raw_copy,
-                                  hipStream_t s) {
+                                  hipStream_t s, void *pairs) {
     hipLaunchKernelGGL(tokens_finalize_kernel, dim3(N * 21), dim3(128), 0, s, tokens, ldt, d, fdim, V, coords, bbox, intr,
-                       pos_mask, pe, raw_copy);
+                       pos_mask, pe, raw_copy, reinterpret_cast<_Float16 *>(pairs));
     return hipGetLastError();
 }
 

@@ -80,6 +80,8 @@ struct HrNet {
 
 struct AttnLayer {
     Layer qkv, out, ff1, ff2;
+    Layer out_x3;   // fp16-kernel modes: to_out once more as a split-pair GEMM (Loader::linear_x3; gemm_x3.hip), fed by attention rows
+                    // written as (hi, lo) pairs; its bias stays with `out` (ff_block_kernel adds it)
     float *n1g = nullptr, *n1b = nullptr, *n2g = nullptr, *n2b = nullptr, *fg = nullptr, *fb = nullptr;
     // learnable-query fusion (layers.py:240-301): the probe block projects only K and V from the tokens; its queries
     // to_q(probe + PE) do not depend on the input and are computed once at load time ([21][2048])
@@ -892,6 +894,13 @@ int hmv_finalize_weights(hmv_handle h) {
             else L.finish(a.qkv, lab + ".qkv", h->ldt, 3 * INNER, 1, 1, d, wt, nullptr, nullptr, nullptr);
         }
         L.linear(a.out, lab + ".to_out", p + ".to_out.weight", p + ".to_out.bias", d, INNER);
+        if (x3lin) {
+            const HostTensor *wo = L.get(p + ".to_out.weight", {d, INNER});
+            if (wo) {
+                const float *o_ = wo->data.data();
+                L.linear_x3(a.out_x3, lab + ".to_out", INNER, d, INNER, [=](int o, int kk) -> float { return o_[(size_t)o * INNER + kk]; });
+            }
+        }
         L.linear(a.ff1, lab + ".ff1", p + ".ff.net.1.weight", p + ".ff.net.1.bias", DHEAD, d);
         L.linear(a.ff2, lab + ".ff2", p + ".ff.net.4.weight", p + ".ff.net.4.bias", d, DHEAD);
         a.n1g = L.vec(p + ".norm1.weight", d); a.n1b = L.vec(p + ".norm1.bias", d);
@@ -1233,21 +1242,26 @@ struct Runner {
     // Everything of a fusion block behind the attention in two launches: the split-K to_out GEMM, then ONE kernel for
     // (slice sum + bias + residual) -> [LayerNorm1] -> FeedForward (LayerNorm, Linear, GELU, Linear, + residual) -> [LayerNorm2]
     // (fusion_kernels.hip).  Same alloc / release sequence in the dry (planning) run.
-    bool ff_fusable(const Layer &out, const Layer &ff1, const Layer &ff2, int rows, int ldt) const {
-        return h->ff_fuse && splitk_slices(out, rows) > 1 && !ff1.f16 && !ff2.f16 && !ff1.plane && !ff2.plane &&
+    bool ff_fusable(const Layer &out, const Layer &ff1, const Layer &ff2, int rows, int ldt, bool have_x3 = false) const {
+        return h->ff_fuse && (have_x3 || splitk_slices(out, rows) > 1) && !ff1.f16 && !ff2.f16 && !ff1.plane && !ff2.plane &&
                ff1.Kpad == ldt && ldt % 16 == 0 && (ff1.Cout == 128 || ff1.Cout == 256) && ff2.Kpad == ff1.Cout && ff2.Cout_pad >= ldt &&
                ldt <= 576;
     }
     void ff_block(const Layer &out, const Layer &ff1, const Layer &ff2, const float *att, int rows, const float *res, int ldr, int rg_out,
                   int rg_in, const float *n1g, const float *n1b, const float *fg, const float *fb, const float *n2g, const float *n2b,
-                  float *y, int ldt, int d, float *y_pairs = nullptr) {
-        const int S = splitk_slices(out, rows), lds_ = (out.Cout + 3) / 4 * 4;
+                  float *y, int ldt, int d, float *y_pairs = nullptr, const Layer *out_x3 = nullptr) {
+        // out_x3: `att` holds (hi, lo) pairs and to_out runs as ONE split-pair GEMM (gemm_x3.hip) instead of four fp32 split-K slices
+        const int S = out_x3 ? 1 : splitk_slices(out, rows), lds_ = (out.Cout + 3) / 4 * 4;
         float *slab = alloc((size_t)S * rows * lds_);
-        Layer Ls = out;
-        Ls.bias = h->zero_bias;
-        ksplit = S;
-        conv(Ls, att, rows, 1, 1, 1, 0, 0, slab, lds_, nullptr, 0, ACT_NONE, 1, 1);
-        ksplit = 1;
+        if (out_x3) {
+            conv(*out_x3, att, rows, 1, 1, 1, 0, 0, slab, lds_, nullptr, 0, ACT_NONE, 1, 1);   // (its own bias is zero)
+        } else {
+            Layer Ls = out;
+            Ls.bias = h->zero_bias;
+            ksplit = S;
+            conv(Ls, att, rows, 1, 1, 1, 0, 0, slab, lds_, nullptr, 0, ACT_NONE, 1, 1);
+            ksplit = 1;
+        }
         if (!dry && rc == HMV_OK) {
             FfBlockParams p{};
             p.slab = slab; p.S = S; p.slice = (size_t)rows * lds_; p.lds = lds_; p.bias0 = out.bias;
@@ -1759,14 +1773,16 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         project(a.qkv, X, rows, qkv, 3 * INNER, Xpairs);
         Xpairs = nullptr;
         float *att = R.alloc((size_t)qrows * INNER);
-        if (Tk > 0) LAUNCH(launch_attention(qkv, B, Tcur, Tq, koff, Tk, att, s));
-        else LAUNCH(hipMemsetAsync(att, 0, (size_t)qrows * INNER * sizeof(float), s));
+        // fp16-kernel modes, fused tail: the attention rows leave the kernel as (hi, lo) pairs and to_out is a split-pair GEMM
+        const bool tx3 = a.out_x3.plane != 0 && R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt, true);
+        if (Tk > 0) LAUNCH(launch_attention(qkv, B, Tcur, Tq, koff, Tk, att, s, tx3 ? 1 : 0));
+        else LAUNCH(hipMemsetAsync(att, 0, (size_t)qrows * INNER * sizeof(float), s));   // (zero rows are zero pairs)
         R.release(qkv);
-        if (R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt)) {   // norm1(to_out + _q) -> FeedForward -> norm2 in one launch behind the GEMM
+        if (R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt, tx3)) {   // norm1(to_out + _q) -> FeedForward -> norm2 in one launch behind the GEMM
             float *Xf = R.alloc((size_t)qrows * ldt);
             if (l + 1 < c.fusion_layers && h->attn[l + 1].qkv.plane) Xpairs = R.alloc((size_t)qrows * ldt);   // the next block's projection input
             R.ff_block(a.out, a.ff1, a.ff2, att, qrows, X, ldt, cross ? Tq : 0, cross ? Tcur : 0, a.n1g, a.n1b, a.fg, a.fb, a.n2g, a.n2b, Xf,
-                       ldt, d, Xpairs);
+                       ldt, d, Xpairs, tx3 ? &a.out_x3 : nullptr);
             R.release(att);
             R.release(X);
             X = Xf;

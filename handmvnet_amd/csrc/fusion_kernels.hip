@@ -33,8 +33,8 @@ __device__ __forceinline__ float fwave_sum(float v) {
 }
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
-constexpr int FF_ROWS = 16;          // token rows per workgroup
-constexpr int FF_WAVES = 8;
+constexpr int FF_WAVES = 8;          // a workgroup takes 16 RB token rows, RB = 1 | 2 (round 4: 32-row tiles when 16-row ones would need
+                                     // more than one round of workgroups: half the weight bytes per token, one round at cfg-3's 5 376 rows)
 // (the kernel runs ONCE per wave: its straight-line code is kept short -- 48 KB of unrolled code cost more in cold instruction
 // fetches than the arithmetic it held)
 
@@ -110,18 +110,21 @@ __device__ __forceinline__ void ln_rows2(ff32x4 (&v)[2][FF_VEC], int d, int lane
 // that are deliberately left in flight across it
 #define FF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// HID = hidden width of the FeedForward: 128 (fusion.py:7-30) or 256 (the learnable-query blocks)
-template <int HID>
+// HID = hidden width of the FeedForward: 128 (fusion.py:7-30) or 256 (the learnable-query blocks); RB = 16-row blocks per workgroup.
+// Row-wise arithmetic, the same MFMA sequence per row whatever RB: a row's bits do not depend on the tile height.
+template <int HID, int RB>
 __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockParams p) {
-    static_assert(FF_ROWS == 2 * FF_WAVES, "a wave owns two token rows");
+    constexpr int FF_ROWS = 16 * RB;         // token rows per workgroup: a wave owns 2 RB of them in the row phases
     constexpr int NV2 = HID / 16;            // 16-wide reduction steps of the second GEMM
     constexpr int NB2 = 5;                   // column blocks of the second GEMM per wave: ceil(36 / 8)
     constexpr bool ALL2 = HID == 128;        // 128-wide hidden layer: all of a wave's W2 vectors fit the registers W1 vacates
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     const int LD = p.ld + 4, LH = HID + 4;
-    float *sN = fsm;                   // [16][LD]  n1 (the FeedForward's residual)
-    float *sF = sN + FF_ROWS * LD;     // [16][LD]  f0, later f2
-    float *sH = sF + FF_ROWS * LD;     // [16][LH]  hidden activations
+    float *sN = fsm;                   // [FF_ROWS][LD]  n1 (the FeedForward's residual)
+    float *sF = sN + FF_ROWS * LD;     // [FF_ROWS][LD]  f0, later f2
+    float *sH = sF + FF_ROWS * LD;     // [FF_ROWS][LH]  hidden activations (phases 1-2); before them: LayerNorm1's and the FeedForward
+                                       // LayerNorm's gamma / beta, [4][ld] (phase 0 only -- the 32-row tile has no LDS to spare)
+    const int hreg = FF_ROWS * LH > 4 * p.ld ? FF_ROWS * LH : 4 * p.ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * FF_ROWS;
     unsigned long long stamp[6] = {};
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockPa
     ff32x4 wv1[FF_NV1];
     const int nv1 = p.ld >> 4, nblk2 = p.ld >> 4;
     wload(wv1, p.w1 + (size_t)wave * 16 * p.ldw1, p.ldw1, nv1, lane);
-    // the three LayerNorms' gamma / beta: staged once per workgroup ([6][ld] floats behind the activation tiles)
-    float *sP = sH + FF_ROWS * LH;
+    // the three LayerNorms' gamma / beta, staged once per workgroup: [4][ld] over the sH region, LayerNorm2's [2][ld] behind it
+    float *sP = sH, *sP2 = sH + hreg;
     {
         const float *src[6] = {p.n1g, p.n1b, p.fg, p.fb, p.n2g, p.n2b};
         float t[6][2];   // ld <= 768 < 2 x 512 threads: every load is issued before the first store
@@ -147,18 +150,20 @@ __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockPa
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int c = tid + 64 * FF_WAVES * u;
-                if (c < p.ld) sP[a * p.ld + c] = t[a][u];
+                if (c < p.ld) (a < 4 ? sP + a * p.ld : sP2 + (a - 4) * p.ld)[c] = t[a][u];
             }
     }
     FF_BARRIER();
 
-    // ---- phase 0: assemble the pre-norm rows, LayerNorm1, the FeedForward's LayerNorm (wave w: rows 2w, 2w + 1, together)
-    {
+    // ---- phase 0: assemble the pre-norm rows, LayerNorm1, the FeedForward's LayerNorm (wave w: rows 2 RB w .. + 2 RB - 1, two at a time)
+#pragma unroll
+    for (int rp = 0; rp < RB; ++rp) {
+        const int lr0 = 2 * RB * wave + 2 * rp;   // first of the pair's two tile rows
         ff32x4 v[2][FF_VEC];
         const int dv = (p.d + 3) & ~3;   // rows are readable up to round4(d): every row stride is a multiple of 4
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int row = min(row0 + 2 * wave + r, p.rows - 1);
+            const int row = min(row0 + lr0 + r, p.rows - 1);
             const float *res = nullptr;
             if (p.res) res = p.res + (size_t)(p.rg_out ? (row / p.rg_out) * p.rg_in + (row % p.rg_out) : row) * p.ldr;
 #pragma unroll
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockPa
 #pragma unroll
             for (int i = 0; i < FF_VEC; ++i) {
                 const int c = 4 * lane + 256 * i;
-                if (c < p.ld) *reinterpret_cast<ff32x4 *>(&sN[(2 * wave + r) * LD + c]) = v[r][i];
+                if (c < p.ld) *reinterpret_cast<ff32x4 *>(&sN[(lr0 + r) * LD + c]) = v[r][i];
             }
         ln_rows2(v, p.d, lane, sP + 2 * p.ld, sP + 3 * p.ld);
 #pragma unroll
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockPa
 #pragma unroll
             for (int i = 0; i < FF_VEC; ++i) {
                 const int c = 4 * lane + 256 * i;
-                if (c < p.ld) *reinterpret_cast<ff32x4 *>(&sF[(2 * wave + r) * LD + c]) = v[r][i];
+                if (c < p.ld) *reinterpret_cast<ff32x4 *>(&sF[(lr0 + r) * LD + c]) = v[r][i];
             }
     }
     FF_BARRIER();
@@ -217,25 +222,29 @@ __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockPa
         const int nb = wave + FF_WAVES * u;
         if (u > 0) wload(wv1, p.w1 + (size_t)nb * 16 * p.ldw1, p.ldw1, nv1, lane);   // (256-wide hidden layer: a second block)
         const float bb = p.b1[nb * 16 + r16];
-        const ff32x4 acc = wmma(sF, LD, wv1, nv1, lane);
+        ff32x4 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = wmma(sF + rb * 16 * LD, LD, wv1, nv1, lane);   // the same weight registers for every row block
         if constexpr (ALL2) {   // the second GEMM's weights, all of this wave's blocks, go out behind the last MFMA of the first
 #pragma unroll
             for (int v2 = 0; v2 < NB2; ++v2)
                 if (wave + FF_WAVES * v2 < nblk2) wload(w2all[v2], p.w2 + (size_t)(wave + FF_WAVES * v2) * 16 * p.ldw2, p.ldw2, NV2, lane);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sH[(4 * g4 + e) * LH + nb * 16 + r16] = gelu_erf(acc[e] + bb);
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sH[(16 * rb + 4 * g4 + e) * LH + nb * 16 + r16] = gelu_erf(acc[rb][e] + bb);
     }
     FF_BARRIER();
     if (p.dbg) stamp[2] = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 2: f2 = h W2^T + b2 + n1 (into sF; columns past d: zero weights, zero bias, zero n1)
-    auto finish2 = [&](int nbx, const ff32x4 &acc) {
+    auto finish2 = [&](int nbx, int rb, const ff32x4 &acc) {
         const int col = nbx * 16 + r16;
         const float bb = p.b2[col];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int lr = 4 * g4 + e;
+            const int lr = 16 * rb + 4 * g4 + e;
             sF[lr * LD + col] = acc[e] + bb + sN[lr * LD + col];
         }
     };
@@ -243,7 +252,10 @@ __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockPa
 #pragma unroll
         for (int v2 = 0; v2 < NB2; ++v2) {
             const int nbx = wave + FF_WAVES * v2;
-            if (nbx < nblk2) finish2(nbx, wmma(sH, LH, w2all[v2], NV2, lane));
+            if (nbx < nblk2) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) finish2(nbx, rb, wmma(sH + rb * 16 * LH, LH, w2all[v2], NV2, lane));
+            }
         }
     } else {
         // this wave's column blocks two at a time: both blocks' weights are requested before either is multiplied
@@ -252,15 +264,20 @@ __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockPa
             const int nb2 = nb + FF_WAVES;
             wload(wa, p.w2 + (size_t)nb * 16 * p.ldw2, p.ldw2, NV2, lane);
             if (nb2 < nblk2) wload(wb, p.w2 + (size_t)nb2 * 16 * p.ldw2, p.ldw2, NV2, lane);
-            finish2(nb, wmma(sH, LH, wa, NV2, lane));
-            if (nb2 < nblk2) finish2(nb2, wmma(sH, LH, wb, NV2, lane));
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                finish2(nb, rb, wmma(sH + rb * 16 * LH, LH, wa, NV2, lane));
+                if (nb2 < nblk2) finish2(nb2, rb, wmma(sH + rb * 16 * LH, LH, wb, NV2, lane));
+            }
         }
     }
     FF_BARRIER();
     if (p.dbg) stamp[3] = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 3: LayerNorm2 (or none) and the output rows, pad columns written as zeros
-    {
+#pragma unroll
+    for (int rp = 0; rp < RB; ++rp) {
+        const int lr0 = 2 * RB * wave + 2 * rp;
         ff32x4 v[2][FF_VEC];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -268,14 +285,14 @@ __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockPa
             for (int i = 0; i < FF_VEC; ++i) {
                 const int c = 4 * lane + 256 * i;
                 v[r][i] = ff32x4{0.f, 0.f, 0.f, 0.f};
-                if (c < p.ld) v[r][i] = *reinterpret_cast<const ff32x4 *>(&sF[(2 * wave + r) * LD + c]);
+                if (c < p.ld) v[r][i] = *reinterpret_cast<const ff32x4 *>(&sF[(lr0 + r) * LD + c]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[r][i][e] = (c + e) < p.d ? v[r][i][e] : 0.f;
             }
-        if (p.n2g) ln_rows2(v, p.d, lane, sP + 4 * p.ld, sP + 5 * p.ld);
+        if (p.n2g) ln_rows2(v, p.d, lane, sP2, sP2 + p.ld);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int row = row0 + 2 * wave + r;
+            const int row = row0 + lr0 + r;
 #pragma unroll
             for (int i = 0; i < FF_VEC; ++i) {
                 const int c = 4 * lane + 256 * i;
@@ -309,19 +326,38 @@ hipError_t launch_ff_block(const FfBlockParams &p, hipStream_t s) {
         p.ld > 16 * FF_NV1 || (p.hid != 128 && p.hid != 256) || p.ldw1 < p.ld || p.ldw2 < p.hid || (p.ldw1 & 3) || (p.ldw2 & 3) || (!p.slab && !p.x) ||
         (p.slab && (p.S < 1 || p.S > 4 || !p.bias0)))
         return hipErrorInvalidValue;
-    const size_t lds = ((size_t)2 * FF_ROWS * (p.ld + 4) + (size_t)FF_ROWS * (p.hid + 4) + (size_t)6 * p.ld) * sizeof(float);
-    static bool configured[64] = {};
+    auto lds_of = [&](int rb) {
+        const size_t rows = 16 * rb, hreg = rows * (p.hid + 4) > (size_t)4 * p.ld ? rows * (p.hid + 4) : (size_t)4 * p.ld;
+        return ((size_t)2 * rows * (p.ld + 4) + hreg + (size_t)2 * p.ld) * sizeof(float);
+    };
+    // 32-row tiles once 16-row ones would not fit one round of workgroups (one per CU: 90 KB of LDS, 240 registers), if they fit LDS
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    static int ncu[64] = {};
+    if (!ncu[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int rb = ((p.rows + 15) / 16 > ncu[dev] && lds_of(2) <= 160 * 1024) ? 2 : 1;
+    const size_t lds = lds_of(rb);
+    static bool configured[64] = {};
     if (!configured[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ff_block_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ff_block_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ff_block_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ff_block_kernel<256, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ff_block_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ff_block_kernel<256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         configured[dev] = true;
     }
-    const dim3 grid((p.rows + FF_ROWS - 1) / FF_ROWS), block(64 * FF_WAVES);
-    if (p.hid == 128) hipLaunchKernelGGL(ff_block_kernel<128>, grid, block, lds, s, p);
-    else hipLaunchKernelGGL(ff_block_kernel<256>, grid, block, lds, s, p);
+    const dim3 grid((p.rows + 16 * rb - 1) / (16 * rb)), block(64 * FF_WAVES);
+    if (p.hid == 128) {
+        if (rb == 2) hipLaunchKernelGGL((ff_block_kernel<128, 2>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((ff_block_kernel<128, 1>), grid, block, lds, s, p);
+    } else {
+        if (rb == 2) hipLaunchKernelGGL((ff_block_kernel<256, 2>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((ff_block_kernel<256, 1>), grid, block, lds, s, p);
+    }
     return hipGetLastError();
 }
 

@@ -56,6 +56,7 @@ struct ConvParams {
     int acc_shift;      // split layers: the packed weights are W * 2^acc_shift (keeps W_lo out of the fp16 subnormals);
     float acc_scale;    //   the epilogue multiplies the accumulator by 2^-acc_shift (filled in by launch_conv)
     int out_split;      // write (hi, lo) pairs (plane stride ldc / 2) instead of one fp16 value
+    int ngroup;         // gemm_x3.hip: > 0 = N-tiles per XCD (each XCD owns a column range of the weights, which then stay in ITS L2)
     int m16;            // fp16 1x1 that multiplies on v_mfma_f32_16x16x32_f16 at every batch size (filled in by launch_conv from conv_m16_rule)
     int tall;           // fp16 3x3 whose weights are packed in conv_ht.hip's K order: that kernel or an error, at every batch size
     int rd_cout;        // row-decomposed 3x3 (narrow Cout): the real channel count; Cout is then 3 * rd_cout, R = 3, S = 1
@@ -152,7 +153,7 @@ hipError_t launch_tokens_finalize(float *tokens, int ldt, int d, int fdim, int N
 hipError_t launch_layernorm(const float *x, int ldx, int rows, int d, const float *g1, const float *b1, float *y,
                             int ldy, const float *g2, const float *b2, float *y2, hipStream_t s);
 // softmax(q k^T / sqrt(128)) v per (sample, head); qkv rows are [q | k | v] of width 3*1024.
-hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s);
+hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s, int pairs = 0);   // pairs: the rows as (hi, lo) fp16 pairs [hi 1024 | lo 1024] instead of fp32
 // MultiHeadAttentionLearnableQuery (layers.py:240-301): softmax(q k^T / sqrt(256)) v per (sample, head), 8 heads x 256.
 // q rows: q + (b * q_bstride + i) * q_ld (q_bstride = 0: the same 21 probe queries for every sample); k / v rows:
 // k + (b * T + j) * kv_ld, j < T.  out [B*Tq][2048].
@@ -201,6 +202,10 @@ bool conv_m16_supported(const ConvParams &p);
 bool conv_m16_rule(const ConvParams &p);
 void conv_m16_set_rule(int on);   // 1 (default) / 0: op-level A/B against the 32x32x16 kernels
 hipError_t launch_conv_m16(ConvParams p, hipStream_t s, const char **name);
+
+// gemm_x3.hip: token GEMMs over (hi, lo) fp16 pairs with fp32 output rows (Loader::linear_x3's packing), at every size
+bool gemm_x3_rule(const ConvParams &p);
+hipError_t launch_gemm_x3(ConvParams p, hipStream_t s, const char **name);
 
 // ---- fusion_kernels.hip: the launch-bound tail as fused kernels
 // Everything of a fusion block behind its to_out GEMM (layers.py:224-233 / 161-174; learnable-query blocks: layers.py:293-299):

@@ -41,6 +41,7 @@ hipError_t launch_nchw_to_nhwc4(const float *x, float *out, int N, int H, int W,
 
 // fp16 path: NCHW fp32 frames -> NHWC8 fp16 (3 real channels + 5 zeros = one 16-byte tap)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __global__ void nchw_to_nhwc8_f16_kernel(const float *__restrict__ x, f16x8 *__restrict__ out, int HW, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -705,7 +706,7 @@ template <int D> struct AttShape {
 // k / v to the first key);  out rows [B * Tq][8 * D]
 template <int D>
 __global__ __launch_bounds__(64 * ATT_WAVES, D == 128 ? HMV_ATT_OCC : 1) void attention_mfma_kernel(const float *__restrict__ q, int q_ld, int q_bstride,
-        const float *__restrict__ k, const float *__restrict__ v, int kv_ld, int T, int Tq, int Tk, int nqb, float *__restrict__ out) {
+        const float *__restrict__ k, const float *__restrict__ v, int kv_ld, int T, int Tq, int Tk, int nqb, float *__restrict__ out, int pairs) {
     using SH = AttShape<D>;
     constexpr int NC = SH::NC, NU = D / 8, NV = D / 32;   // K vectors per lane, V vectors per lane and quarter chunk
     extern __shared__ __attribute__((aligned(16))) float att_smem[];
@@ -872,14 +873,29 @@ __global__ __launch_bounds__(64 * ATT_WAVES, D == 128 ? HMV_ATT_OCC : 1) void at
                     for (int w = 0; w < ATT_WAVES; ++w) num += sO[((w * NC + c) * 16 + 4 * g + e2) * 64 + lane] * a[w];
                     r4[e2] = num * inv;
                 }
-                if (row < Tq) *reinterpret_cast<f32x4 *>(out + ((size_t)b * Tq + row) * (8 * D) + h * D + 32 * c + 8 * g + 4 * kh) = r4;
+                if (row < Tq) {
+                    if (pairs) {   // the rows as (hi, lo) fp16 pairs [hi 8 D | lo 8 D] for a split-pair to_out GEMM (gemm_x3.hip): split_f16's arithmetic
+                        f16x4 hi4, lo4;
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) {
+                            _Float16 a_, b_;
+                            split_f16(r4[e2], a_, b_);
+                            hi4[e2] = a_; lo4[e2] = b_;
+                        }
+                        _Float16 *pr = reinterpret_cast<_Float16 *>(out) + ((size_t)b * Tq + row) * (16 * D) + h * D + 32 * c + 8 * g + 4 * kh;
+                        *reinterpret_cast<f16x4 *>(pr) = hi4;
+                        *reinterpret_cast<f16x4 *>(pr + 8 * D) = lo4;
+                    } else {
+                        *reinterpret_cast<f32x4 *>(out + ((size_t)b * Tq + row) * (8 * D) + h * D + 32 * c + 8 * g + 4 * kh) = r4;
+                    }
+                }
             }
         }
     }
 }
 template <int D>
 static hipError_t launch_attention_any(const float *q, int q_ld, int q_bstride, const float *k, const float *v, int kv_ld, int B, int T, int Tq,
-                                       int Tk, float *out, hipStream_t s) {
+                                       int Tk, float *out, hipStream_t s, int pairs = 0) {
     if (Tk <= 0 || Tq <= 0 || B <= 0) return hipErrorInvalidValue;
     static bool configured[64] = {};
     int dev = 0;
@@ -892,11 +908,11 @@ static hipError_t launch_attention_any(const float *q, int q_ld, int q_bstride, 
     }
     const int nqb = (Tq + 31) >> 5;
     hipLaunchKernelGGL(attention_mfma_kernel<D>, dim3((unsigned)B * 8 * nqb), dim3(64 * ATT_WAVES), lds, s, q, q_ld, q_bstride, k, v, kv_ld, T, Tq,
-                       Tk, nqb, out);
+                       Tk, nqb, out, pairs);
     return hipGetLastError();
 }
-hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s) {
-    return launch_attention_any<128>(qkv, 3 * 1024, T, qkv + (size_t)koff * 3072 + 1024, qkv + (size_t)koff * 3072 + 2048, 3 * 1024, B, T, Tq, Tk, out, s);
+hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s, int pairs) {
+    return launch_attention_any<128>(qkv, 3 * 1024, T, qkv + (size_t)koff * 3072 + 1024, qkv + (size_t)koff * 3072 + 2048, 3 * 1024, B, T, Tq, Tk, out, s, pairs);
 }
 
 // ------------------------------------------------------------------ learnable-query fusion

@@ -356,6 +356,19 @@ def test_conv_kernel_split_precision_vs_torch(shape):
     assert _run_conv(shape, 2) < 3e-6
 
 
+# plain GEMMs over split rows with fp32 output rows and a long reduction (gemm_x3.hip: to_out of the fusion blocks in the fp16-kernel
+# modes, layers.py:224: K = 1 024, 524 columns -- no multiple of the tile; the learnable-query blocks' K = 2 048): both tile sizes,
+# ragged row counts; and the shorter reductions that stay on conv_igemm's fused split loop (the q / k / v projections, K = 544)
+X3_SHAPES = [(3, 21, 8, 1024, 524, 1, 1, 0, False, False), (40, 21, 8, 1024, 524, 1, 1, 0, False, False), (1, 1, 33, 1024, 128, 1, 1, 0, False, False),
+             (2, 16, 16, 2048, 312, 1, 1, 0, False, False), (1, 7, 3, 1024, 64, 1, 1, 0, False, False), (3, 21, 8, 544, 3072, 1, 1, 0, False, False)]
+
+
+@pytest.mark.parametrize("shape", X3_SHAPES)
+def test_split_pair_gemm_vs_torch(shape):
+    """gemm_x3.hip against torch fp64: fp32-grade error (hi + lo carries 22 bits, the dropped lo * lo term is 2^-22 relative)."""
+    assert _run_conv(shape, 2) < 3e-6
+
+
 @pytest.mark.parametrize("shape", HALF_SHAPES)
 def test_conv_kernel_fp16_vs_torch(shape):
     """... and with plain fp16 operands, fp32 accumulation: fp16-grade error."""

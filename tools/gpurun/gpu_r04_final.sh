@@ -1,5 +1,5 @@
-# round 3: the bench records of the round, one box
-O=gpurun_out/r03final; mkdir -p $O
+# round 4: the bench records of the round, one box
+O=gpurun_out/r04final; mkdir -p $O
 run() { name=$1; shift; timeout -k 10 400 python bench.py "$@" > $O/$name.json 2> $O/$name.err || { echo "FAILED $name"; tail -5 $O/$name.err; exit 70; }; python -c "
 import json; d=json.load(open('$O/$name.json')); print('$name', d['ms_per_step'], d['value'], d['dtype'], d.get('launches_per_forward'), d['roofline']['kernel'], d['roofline']['frac'], d['forward'])"; }
 run bench_default

@@ -65,11 +65,22 @@ def family(name: str) -> str:
         return f"conv_rds_f32<3x3,{m.group(1)}->{m.group(1)}" + (",res>" if m.group(2) == "true" else ">")
     if re.match(r"(?:void )?(?:hmv::)?conv_hs_stem_f32<", name):
         return "conv_hs_stem_f32<4x4,12->64>"
-    if re.match(r"(?:void )?(?:hmv::)?conv_ht_f16\b", name) or name.startswith("_ZN3hmv11conv_ht_f16"):
-        return "conv_ht_f16<512x128,3x3>"
-    m = re.match(r"(?:void )?(?:hmv::)?conv_gemm8_f16<(true|false)>", name)
+    # round 4: conv_ht_f16<M16>, conv_gemm8_f16<DUAL, M16>, conv_m16_f16<BM, BN, TAPS, DUAL>, gemm_x3_f16<BM, BN, WGM, WGN> (demangled or not)
+    m = re.match(r"(?:void )?(?:hmv::)?conv_ht_f16<(true|false)>", name) or re.match(r"_ZN3hmv11conv_ht_f16ILb([01])EE", name)
     if m:
-        return "conv_gemm8_f16<256x256,1x1" + (",dual>" if m.group(1) == "true" else ">")
+        return "conv_ht_f16<512x128,3x3" + (",m16>" if m.group(1) in ("true", "1") else ">")
+    m = re.match(r"(?:void )?(?:hmv::)?conv_gemm8_f16<(true|false)(?:, (true|false))?>", name) or re.match(r"_ZN3hmv14conv_gemm8_f16ILb([01])ELb([01])EE", name)
+    if m:
+        dual, m16 = m.group(1) in ("true", "1"), m.group(2) in ("true", "1")
+        return "conv_gemm8_f16<256x256,1x1" + (",dual" if dual else "") + (",m16>" if m16 else ">")
+    m = re.match(r"(?:void )?(?:hmv::)?conv_m16_f16<(\d+), (\d+), (true|false)(?:, (true|false))?>", name) or \
+        re.match(r"_ZN3hmv12conv_m16_f16ILi(\d+)ELi(\d+)ELb([01])ELb([01])EE", name)
+    if m:
+        taps, dual = m.group(3) in ("true", "1"), m.group(4) in ("true", "1")
+        return f"conv_m16_f16<{m.group(1)}x{m.group(2)}," + ("taps,c32>" if taps else ("1x1,dual>" if dual else "1x1>"))
+    m = re.match(r"(?:void )?(?:hmv::)?gemm_x3_f16<(\d+), (\d+), \d+, \d+>", name) or re.match(r"_ZN3hmv11gemm_x3_f16ILi(\d+)ELi(\d+)E", name)
+    if m:
+        return f"gemm_x3_f16<{m.group(1)}x{m.group(2)}>"
     return re.sub(r"\(.*", "", name).replace("void ", "").replace("hmv::", "")
 
 

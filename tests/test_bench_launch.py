@@ -86,11 +86,18 @@ def test_pmc_summary_names_the_round3_kernels_like_the_engine_does():
     assert ps.family("void hmv::conv_stream_f16<2, 2, 1, 8, 4, 4, true, true, 0, false>(hmv::ConvParams)") == "conv_stream_f16<64x512,k256,res>"
     assert ps.family("void hmv::conv_stream_f16<1, 2, 8, 1, 4, 4, false, false, 0, false>(hmv::ConvParams)") == "conv_stream_f16<256x64,k256>"
     assert ps.family("void hmv::conv_stream_f16<2, 2, 2, 4, 2, 8, false, false, 0, true>(hmv::ConvParams)") == "conv_stream_f16<128x256,k128,dual>"
-    assert ps.family("void hmv::conv_gemm8_f16<true>(hmv::ConvParams)") == "conv_gemm8_f16<256x256,1x1,dual>"
+    assert ps.family("void hmv::conv_gemm8_f16<true, false>(hmv::ConvParams)") == "conv_gemm8_f16<256x256,1x1,dual>"
+    # round 4: the 16x16x32-MFMA instantiations and their small-launch companions
+    assert ps.family("void hmv::conv_gemm8_f16<false, true>(hmv::ConvParams)") == "conv_gemm8_f16<256x256,1x1,m16>"
+    assert ps.family("void hmv::conv_gemm8_f16<true, true>(hmv::ConvParams)") == "conv_gemm8_f16<256x256,1x1,dual,m16>"
+    assert ps.family("void hmv::conv_ht_f16<true>(hmv::ConvParams)") == "conv_ht_f16<512x128,3x3,m16>"
+    assert ps.family("_ZN3hmv11conv_ht_f16ILb0EEEvNS_10ConvParamsE.kd") == "conv_ht_f16<512x128,3x3>"
+    assert ps.family("void hmv::conv_m16_f16<64, 64, true, false>(hmv::ConvParams)") == "conv_m16_f16<64x64,taps,c32>"
+    assert ps.family("void hmv::conv_m16_f16<128, 128, false, true>(hmv::ConvParams)") == "conv_m16_f16<128x128,1x1,dual>"
+    assert ps.family("void hmv::gemm_x3_f16<128, 128, 4, 2>(hmv::ConvParams)") == "gemm_x3_f16<128x128>"
     assert ps.family("void hmv::conv_hs_f16<3, 3, 8, 2, 1, 4, 2, 3, false>(hmv::ConvParams)") == "conv_hs_f16<3x3,64->64>"
     assert ps.family("void hmv::conv_hs_f16<3, 3, 5, 2, 1, 4, 2, 3, true>(hmv::ConvParams)") == "conv_hs_f16<3x3,40->40,res>"
     assert ps.family("void hmv::conv_hs_f16<4, 4, 2, 2, 1, 4, 2, 4, false>(hmv::ConvParams)") == "conv_hs_f16<4x4,16->64>"
-    assert ps.family("hmv::conv_ht_f16(hmv::ConvParams)") == "conv_ht_f16<512x128,3x3>"
     # the chained / pooled launches (template arguments N2 and POOL)
     assert ps.family("void hmv::conv_stream_f16<2, 2, 2, 4, 2, 8, false, false, 0, true, 0>(hmv::ConvParams)") == "conv_stream_f16<128x256,k128,dual>"
     assert ps.family("void hmv::conv_stream_f16<2, 2, 2, 4, 2, 4, false, false, 0, true, 64>(hmv::ConvParams)") == "conv_stream_f16<128x256,k128,dual,+1x1:64>"

@@ -81,7 +81,12 @@ __global__ __launch_bounds__(64 * MW * NW, ((MW * NW >= 4) ? 2 : 1)) void conv_h
     static_assert(!POOL || (!HAS_RES && BH == 16 && (NT == 512 || NT == 256) && TN * NW == 2), "pooled epilogue: 16 x 16 blocks of 64 channels, 512 pooling tasks");
     constexpr int ZW = TM * TN * 2 * 1024;
     constexpr int NSTEP = (NCH + 1) / 2;
-    constexpr bool SWZ = CPP == 8;                     // 128-byte pixels: XOR swizzle; 80- / 32-byte pixels are conflict-free as they lie
+    constexpr bool SWZ = CPP == 8;                     // 128-byte pixels: XOR swizzle; 80-byte pixels are conflict-free as they lie.
+    // 32-byte pixels (the space-to-depth stem) are not -- a ds_read_b128's 16-lane service group {0-3, 12-15, 20-27} lands on the 8 even
+    // (or odd) 16-byte slots: two-way conflicts, the 0.121 LDS conflicts per wave-cycle of the r03 PMC summary -- and they stay that way:
+    // chunk ^ (halo column & 1) removes every conflict (tools/probe/swizzle_search.py --stem) and was measured on one box in round 4
+    // (gpurun_out/r04/pl_swz*.json vs pl_ref*.json): 243 / 229 us against 225 / 222 us.  The pooled stem is bound by vector-instruction
+    // issue, not by LDS cycles; the second base register per pixel block cost more than the conflicts.
     static_assert(NWV <= 8 && (BH == 16 || BH == 8), "at most eight waves over 16 x 16 or 8 x 16 output blocks");
     extern __shared__ __attribute__((aligned(16))) char hsm[];
     char *zones = hsm + NSLOT * SLOT;                  // [2][NWV][ZW]

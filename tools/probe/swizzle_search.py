@@ -45,3 +45,29 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def stem_main():
+    """`--stem`: 32-byte halo pixels (the fp16 space-to-depth stem of conv_hs.hip, 2 chunks per pixel, 32x32x16 lane map: lanes 0-31
+    are rows r (lanes 0-15) and r + 1 (16-31) x 16 columns of one k-half).  Unswizzled, a service group's 16 lanes use 8 slots."""
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+
+    def ok(pitch, g, taps=4):
+        for dy in range(taps):
+            for dx in range(taps):
+                for r0 in (0, 2, 4, 6):
+                    for ch in (0, 1):
+                        for grp in groups:
+                            seen = set()
+                            for lane in grp:
+                                row, col = r0 + (lane >> 4) + dy, (lane & 15) + dx
+                                slot = (2 * (row * pitch + col) + (ch ^ g(row, col))) % 16
+                                if slot in seen:
+                                    return False
+                                seen.add(slot)
+        return True
+    print("19-pixel rows, unswizzled:", ok(19, lambda r, c: 0), " chunk ^ (column & 1):", ok(19, lambda r, c: c & 1))
+
+
+if __name__ == "__main__" and "--stem" in __import__("sys").argv:
+    stem_main()

@@ -872,6 +872,13 @@ int hmv_finalize_weights(hmv_handle h) {
                 }
             }
             L.linear(a.out, lab + ".to_out", p + ".to_out.0.weight", p + ".to_out.0.bias", d, INNER_LQ);
+            if (x3lin) {   // fp16-kernel modes: to_out once more as a split-pair GEMM (gemm_x3.hip), as in CrossAttentionFusion below
+                const HostTensor *wo = L.get(p + ".to_out.0.weight", {d, INNER_LQ});
+                if (wo) {
+                    const float *o_ = wo->data.data();
+                    L.linear_x3(a.out_x3, lab + ".to_out", INNER_LQ, d, INNER_LQ, [=](int o, int kk) -> float { return o_[(size_t)o * INNER_LQ + kk]; });
+                }
+            }
             L.linear(a.ff1, lab + ".ff1", p + ".ff.net.1.weight", p + ".ff.net.1.bias", DHEAD_LQ, d);
             L.linear(a.ff2, lab + ".ff2", p + ".ff.net.4.weight", p + ".ff.net.4.bias", d, DHEAD_LQ);
             a.fg = L.vec(p + ".ff.net.0.weight", d); a.fb = L.vec(p + ".ff.net.0.bias", d);
@@ -1717,23 +1724,24 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
             LAUNCH(launch_add_pe(X, ldt, rows, Tcur, d, h->pe, xp, ldt, s));
             R.release(X);
             float *att = R.alloc((size_t)qrows * INNER_LQ);
+            const bool tx3 = a.out_x3.plane != 0 && R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt, true);   // attention rows as (hi, lo) pairs
             if (cross) {
                 float *kv = R.alloc((size_t)rows * 2 * INNER_LQ);
                 project(a.kv, xp, rows, kv, 2 * INNER_LQ);
-                LAUNCH(launch_attention_d256(a.qprobe, INNER_LQ, 0, kv, kv + INNER_LQ, 2 * INNER_LQ, B, Tcur, Tq, att, s));
+                LAUNCH(launch_attention_d256(a.qprobe, INNER_LQ, 0, kv, kv + INNER_LQ, 2 * INNER_LQ, B, Tcur, Tq, att, s, tx3 ? 1 : 0));
                 R.release(kv);
             } else {
                 float *qkv = R.alloc((size_t)rows * 3 * INNER_LQ);
                 project(a.qkv, xp, rows, qkv, 3 * INNER_LQ);
-                LAUNCH(launch_attention_d256(qkv, 3 * INNER_LQ, Tcur, qkv + INNER_LQ, qkv + 2 * INNER_LQ, 3 * INNER_LQ, B, Tcur, Tq, att, s));
+                LAUNCH(launch_attention_d256(qkv, 3 * INNER_LQ, Tcur, qkv + INNER_LQ, qkv + 2 * INNER_LQ, 3 * INNER_LQ, B, Tcur, Tq, att, s, tx3 ? 1 : 0));
                 R.release(qkv);
             }
-            if (R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt)) {
+            if (R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt, tx3)) {
                 // out = to_out(att) (+ x, not in the probe block); out = ff(out) + out: no LayerNorm around the attention, the
                 // FeedForward keeps its own; pad columns come out as zeros
                 float *Xf = R.alloc((size_t)qrows * ldt);
                 R.ff_block(a.out, a.ff1, a.ff2, att, qrows, cross ? nullptr : xp, ldt, 0, 0, nullptr, nullptr, a.fg, a.fb, nullptr, nullptr,
-                           Xf, ldt, d);
+                           Xf, ldt, d, nullptr, tx3 ? &a.out_x3 : nullptr);
                 R.release(att);
                 R.release(xp);
                 X = Xf;

@@ -158,7 +158,7 @@ hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, in
 // q rows: q + (b * q_bstride + i) * q_ld (q_bstride = 0: the same 21 probe queries for every sample); k / v rows:
 // k + (b * T + j) * kv_ld, j < T.  out [B*Tq][2048].
 hipError_t launch_attention_d256(const float *q, int q_ld, int q_bstride, const float *k, const float *v, int kv_ld, int B, int T,
-                                 int Tq, float *out, hipStream_t s);
+                                 int Tq, float *out, hipStream_t s, int pairs = 0);
 // y[r][c] = x[r][c] + pe[r % T][c] for c < d, 0 for d <= c < ldy (PositionalEncoding inside every learnable-query block)
 hipError_t launch_add_pe(const float *x, int ldx, int rows, int T, int d, const float *pe, float *y, int ldy, hipStream_t s);
 // split-K GEMM tail: out[r][c] = act(sum_s slab[s][r][c] + bias[c] + res[r'][c]) for c < N (slices summed in index order)

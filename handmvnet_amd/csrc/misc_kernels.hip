@@ -976,11 +976,11 @@ __global__ __launch_bounds__(256) void attention_d256_kernel(const float *__rest
     }
 }
 hipError_t launch_attention_d256(const float *q, int q_ld, int q_bstride, const float *k, const float *v, int kv_ld, int B, int T,
-                                 int Tq, float *out, hipStream_t s) {
+                                 int Tq, float *out, hipStream_t s, int pairs) {
     if (T <= 0 || Tq <= 0) return hipErrorInvalidValue;
     // QK^T and PV on the fp32 matrix cores like the 128-wide heads (the same kernel template, D = 256); HMV_LQ_SCALAR_ATT=1
     // keeps the wave-per-query-row form below (A/B runs, read per launch)
-    if (!HMV_DEV_ENV("HMV_LQ_SCALAR_ATT")) return launch_attention_any<256>(q, q_ld, q_bstride, k, v, kv_ld, B, T, Tq, T, out, s);
+    if (pairs || !HMV_DEV_ENV("HMV_LQ_SCALAR_ATT")) return launch_attention_any<256>(q, q_ld, q_bstride, k, v, kv_ld, B, T, Tq, T, out, s, pairs);
     hipLaunchKernelGGL(attention_d256_kernel, dim3(B * 8), dim3(256), 0, s, q, q_ld, q_bstride, k, v, kv_ld, T, Tq, out);
     return hipGetLastError();
 }

@@ -1378,6 +1378,7 @@ hipError_t launch_conv(ConvParams p, ConvTile tile, hipStream_t s, const char **
     // token GEMMs over (hi, lo) fp16 pairs with fp32 output rows (the fusion blocks' q / k / v projections in the fp16-kernel modes):
     // gemm_x3.hip at every size (a four-stage ring on the 16x16x32 MFMA instead of the fused split loop's one DMA in flight)
     if (!generic && gemm_x3_rule(p)) return launch_gemm_x3(p, s, name);
+    if (!generic && gemm_x3k16_ok(p)) return launch_gemm_x3k16(p, s, name);
     // MFMA-heavy fp16 1x1 convs without a residual (layer3's conv1, pose_net.0): the 16x16x32 MFMA at EVERY batch size -- the
     // phase-interleaved 256 x 256 tile where its tiles fill the chip, conv_m16.hip's small tiles elsewhere (same bits)
     if (!generic && conv_m16_rule(p)) {

@@ -2085,6 +2085,12 @@ int hmv_set_tail_fusion(hmv_handle h, int32_t enable) {
 
 /* Chained launches (Bottleneck conv3 -> the next block's conv1 from the output tile in LDS) on (default) / off (one launch per conv:
  * the same bits).  Part of the workspace plan, so the workspace is re-planned on the next forward. */
+int hmv_set_x3k16_mode(int32_t mode) {
+    if (mode < -1 || mode > 1) { g_create_err = "hmv_set_x3k16_mode: -1, 0 or 1"; return HMV_ERR_ARG; }
+    gemm_x3k16_set_mode(mode);
+    return HMV_OK;
+}
+
 int hmv_set_chain_fusion(hmv_handle h, int32_t enable) {
     if (!h) return HMV_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));

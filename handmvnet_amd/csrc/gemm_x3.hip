@@ -202,6 +202,200 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_x3_f16(const ConvParams p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// gemm_x3k16_f16: the q / k / v projections at LARGE row counts (layers.py:213-215; cfg-3: 5 376 rows x 3 072 columns, K = 544 pairs).
+// conv_igemm's fused split loop runs them on 128 x 128 tiles, two workgroups per CU, ONE DMA in flight per workgroup: ~36 us per tile for
+// 5.9 us of MFMA time (17 k-steps of one exposed operand round trip each), 72 us per launch whatever the tile size.
+// Here: 256 x 256 tiles (half the operand bytes through the CUs: 281 instead of 562 MB), eight waves (2 x 4, a wave owns 128 x 64),
+// k-steps of SIXTEEN channels -- 64-byte LDS rows [16 hi | 16 lo], 32 KB per stage -- on a ring of four stages with three tiles in flight
+// and one counted `s_waitcnt vmcnt(N)` + barrier per step.  Per 32 x 32 block and step three v_mfma_f32_32x32x16_f16 -- hi*hi, lo*hi,
+// hi*lo -- which is EXACTLY the fused split loop's sequence per 16-channel group (weights as the A operand, bias / 2^shift as the
+// accumulators' initial value, (acc * 2^-shift + 0) in the epilogue): the results are bit-identical to that loop's
+// (tests/test_gpu_parity.py::test_split_pair_gemm_large_tiles_are_bit_identical), so the launcher may pick by size.
+typedef float xf32x16 __attribute__((ext_vector_type(16)));
+constexpr int XK_NS = 4, XK_STAGE = 512 * 64, XK_LDS = XK_NS * XK_STAGE;   // 131 072
+
+__global__ __launch_bounds__(512, 2) void gemm_x3k16_f16(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char ksm[];   // [XK_NS][256 token rows + 256 weight rows][64 bytes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5, wm = wave >> 2, wn = wave & 3;
+    int mt, nt;
+    {   // the N-tiles of a row tile are consecutive workgroups of one XCD (bijective for any grid size)
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, r = nblk & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        mt = lid / p.ntiles;
+        nt = lid - mt * p.ntiles;
+    }
+    const _Float16 *zero16 = reinterpret_cast<const _Float16 *>(p.zero);
+    const int nk = p.x3_plane >> 4;   // 16-channel steps
+
+    // ---- DMA roles: thread -> row tid >> 2 of each 128-row pass, physical chunk tid & 3 holding logical chunk (tid & 3) ^ ((row >> 2) & 3):
+    // logical chunks 0, 1 = the step's 16 hi channels, 2, 3 = its 16 lo channels
+    const int lrow = tid >> 2, lc = (tid & 3) ^ ((lrow >> 2) & 3);
+    const _Float16 *aptr[2], *wptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mt * 256 + i * 128 + lrow;
+        aptr[i] = m < p.M ? reinterpret_cast<const _Float16 *>(p.in) + (size_t)m * p.lda + (lc < 2 ? 8 * lc : p.x3_plane + 8 * (lc - 2)) : nullptr;
+        // packed weights: per 32-channel step 32 hi values then 32 lo values
+        wptr[i] = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(nt * 256 + i * 128 + lrow) * p.ldw + (lc < 2 ? 8 * lc : 32 + 8 * (lc - 2));
+    }
+    int ck = 0;
+    auto dma = [&]() {   // the tile of step ck into stage ck & 3, then advance (past the end: dummies from the zero page)
+        char *st = ksm + (ck & (XK_NS - 1)) * XK_STAGE;
+        const bool live = ck < nk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const _Float16 *src = (live && aptr[i]) ? aptr[i] + 16 * ck : zero16;
+            asm volatile("" : "+v"(src));
+            HMV_XGLDS16(src, st + (i * 128 + wave * 16) * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const _Float16 *src = live ? wptr[i] + 64 * (ck >> 1) + 16 * (ck & 1) : zero16;
+            asm volatile("" : "+v"(src));
+            HMV_XGLDS16(src, st + (256 + i * 128 + wave * 16) * 64);
+        }
+        ++ck;
+    };
+
+    // ---- accumulators start at the bias: register 4 q + t of block (a, b) = column 32 b + 8 q + 4 kh + t of row 32 a + l31 (conv_igemm's
+    // transposed-output map for 32-bit rows)
+    xf32x16 acc[4][2];
+    {
+        const float binit = 1.f / p.acc_scale;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float *bp = p.bias + nt * 256 + wn * 64 + 32 * b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const xf32x4 bq = *reinterpret_cast<const xf32x4 *>(bp + 8 * q + 4 * kh);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[a][b][4 * q + t] = bq[t] * binit;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(acc[a][b]));
+
+    const int fkey = (l31 >> 2) & 3;
+    const int foff_a = (wm * 128 + l31) * 64, foff_w = (256 + wn * 64 + l31) * 64;
+    const int ch_hi = (kh ^ fkey) * 16, ch_lo = ((2 + kh) ^ fkey) * 16;
+    xf16x8 ah0[4], al0[4], wh0[2], wl0[2], ah1[4], al1[4], wh1[2], wl1[2];
+#define XK_READ(AH, AL, WH, WL, kt_)                                                                        \
+    {                                                                                                       \
+        const char *st_ = ksm + ((kt_) & (XK_NS - 1)) * XK_STAGE;                                           \
+        _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) {                                                  \
+            WH[b_] = *reinterpret_cast<const xf16x8 *>(st_ + foff_w + b_ * 2048 + ch_hi);                   \
+            WL[b_] = *reinterpret_cast<const xf16x8 *>(st_ + foff_w + b_ * 2048 + ch_lo);                   \
+        }                                                                                                   \
+        _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_) {                                                  \
+            AH[a_] = *reinterpret_cast<const xf16x8 *>(st_ + foff_a + a_ * 2048 + ch_hi);                   \
+            AL[a_] = *reinterpret_cast<const xf16x8 *>(st_ + foff_a + a_ * 2048 + ch_lo);                   \
+        }                                                                                                   \
+    }
+#define XK_MFMA(AH, AL, WH, WL)                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                                        \
+        _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                                    \
+            acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[b_], AH[a_], acc[a_][b_], 0, 0, 0);     \
+    _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                                        \
+        _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                                    \
+            acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[b_], AL[a_], acc[a_][b_], 0, 0, 0);     \
+    _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                                        \
+        _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                                    \
+            acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WL[b_], AH[a_], acc[a_][b_], 0, 0, 0);     \
+    __builtin_amdgcn_s_setprio(0);
+
+    dma();
+    dma();
+    dma();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed (two tiles of 4 DMAs may fly)
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    XK_READ(ah0, al0, wh0, wl0, 0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // tile kt + 1 landed; this wave's reads of tile kt - 1 are done
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        dma();
+        XK_READ(ah1, al1, wh1, wl1, kt + 1);
+        XK_MFMA(ah0, al0, wh0, wl0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 >= nk) break;
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        dma();
+        XK_READ(ah0, al0, wh0, wl0, kt + 2);
+        XK_MFMA(ah1, al1, wh1, wl1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#undef XK_READ
+#undef XK_MFMA
+
+    // ---- epilogue (conv_igemm's register path for 32-bit rows without a residual: acc * 2^-shift + 0, no activation)
+    const int nb0 = nt * 256 + wn * 64;
+    const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 3) & ~3);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int m = mt * 256 + wm * 128 + 32 * a + l31;
+        float *orow = reinterpret_cast<float *>(p.out) + (size_t)m * p.ldc;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = nb0 + 32 * b + 8 * q + 4 * kh;
+                xf32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = fmaxf(acc[a][b][4 * q + t] * p.acc_scale + 0.f, -INFINITY);
+                if (m < p.M && col < cend) *reinterpret_cast<xf32x4 *>(orow + col) = v;
+            }
+    }
+}
+
+// the launches it takes: the split-pair GEMM rule below with a SHORT reduction (the long ones run gemm_x3_f16), whole 256-column tiles,
+// and enough of them to fill most of the chip -- a size rule, legitimate because the bits equal the fused split loop's
+static int g_x3k16_mode = -1;   // -1 the size rule, 0 never, 1 whenever the shape allows (op-level tests)
+void gemm_x3k16_set_mode(int mode) { g_x3k16_mode = mode; }
+bool gemm_x3k16_ok(const ConvParams &p) {
+    if (g_x3k16_mode == 0) return false;
+    if (!p.in_f16 || p.out_f16 || p.out_split || p.res || p.in2 || p.up || p.ksl > 1 || p.phases > 1 || p.cwrap || !p.x3_plane || p.rd_cout ||
+        p.scatter || p.rg_out || p.nx_wgt || p.pool || p.tall || p.act != ACT_NONE || p.fill)
+        return false;
+    const int ldw = p.ldw ? p.ldw : p.Kpad;
+    if (!(p.R == 1 && p.S == 1 && p.stride == 1 && !p.pad_h && !p.pad_w && p.x3_plane % 32 == 0 && p.x3_plane < 1024 && p.Kpad == 2 * p.x3_plane &&
+          p.lda >= 2 * p.x3_plane && !(p.lda & 7) && !(ldw & 7) && !(p.ldc & 3) && p.Ho == p.H && p.Wo == p.W && p.Cout % 256 == 0))
+        return false;
+    if (g_x3k16_mode > 0) return true;
+    return (long long)((p.M + 255) / 256) * (p.Cout / 256) >= 200;
+}
+hipError_t launch_gemm_x3k16(ConvParams p, hipStream_t s, const char **name) {
+    if (!gemm_x3k16_ok(p)) return hipErrorInvalidValue;
+    if (!p.ldw) p.ldw = p.Kpad;
+    static bool configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!configured[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_x3k16_f16), hipFuncAttributeMaxDynamicSharedMemorySize, XK_LDS);
+        if (e != hipSuccess) return e;
+        configured[dev] = true;
+    }
+    p.mtiles = (p.M + 255) / 256;
+    p.ntiles = p.Cout / 256;
+    if (name) *name = "gemm_x3k16_f16<256x256>";
+    hipLaunchKernelGGL(gemm_x3k16_f16, dim3(p.mtiles * p.ntiles), dim3(512), XK_LDS, s, p);
+    return hipGetLastError();
+}
+
 // ====================================================================== host side
 // The layers it takes: plain GEMMs over split token rows with fp32 output rows (Loader::linear_x3's packing), no epilogue beyond the
 // bias.  A rule on the layer alone -- never on the number of rows.

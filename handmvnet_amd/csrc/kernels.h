@@ -206,6 +206,11 @@ hipError_t launch_conv_m16(ConvParams p, hipStream_t s, const char **name);
 // gemm_x3.hip: token GEMMs over (hi, lo) fp16 pairs with fp32 output rows (Loader::linear_x3's packing), at every size
 bool gemm_x3_rule(const ConvParams &p);
 hipError_t launch_gemm_x3(ConvParams p, hipStream_t s, const char **name);
+// ... and the short-reduction ones (q / k / v projections) at large row counts: 256 x 256 tiles on a deep ring, bit-identical to
+// conv_igemm's fused split loop (so chosen by size)
+bool gemm_x3k16_ok(const ConvParams &p);
+void gemm_x3k16_set_mode(int mode);   // -1 the size rule, 0 never, 1 whenever the shape allows (op-level tests)
+hipError_t launch_gemm_x3k16(ConvParams p, hipStream_t s, const char **name);
 
 // ---- fusion_kernels.hip: the launch-bound tail as fused kernels
 // Everything of a fusion block behind its to_out GEMM (layers.py:224-233 / 161-174; learnable-query blocks: layers.py:293-299):

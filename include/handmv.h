@@ -165,6 +165,12 @@ int hmv_op_conv2d(int32_t device, const float *in, int32_t N, int32_t H, int32_t
                   const float *weight_oihw_host, const float *bias_host, int32_t Cout, int32_t R, int32_t S,
                   int32_t stride, int32_t pad, const float *residual, int32_t relu, float *out, void *stream);
 
+/* TEST HOOK (process-global, single-threaded like the kernel_sel entries below): which kernel the split-pair token GEMMs with a short
+ * reduction (the q / k / v projections of the fp16-kernel modes: layers.py:213-215) take -- -1 the engine's size rule (gemm_x3.hip's
+ * 256 x 256 tiles from ~200 tiles up, conv_igemm's fused split loop below), 0 never the 256 x 256 tiles, 1 whenever the shape allows.
+ * The two give the same bits; the identity test drives both through hmv_op_conv2d_ex(dtype = HMV_F32X3). */
+int hmv_set_x3k16_mode(int32_t mode);
+
 /* The same op in any arithmetic mode (dtype = HMV_F32 | HMV_F16 | HMV_F32X3): the fp32 input / residual are converted to the
  * mode's storage format on the device, the layer is packed exactly as hmv_finalize_weights packs it (no BatchNorm), the
  * output is fp32.  Cin must be a multiple of 8 for the fp16-based modes. */

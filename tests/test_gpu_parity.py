@@ -369,6 +369,40 @@ def test_split_pair_gemm_vs_torch(shape):
     assert _run_conv(shape, 2) < 3e-6
 
 
+# q / k / v projection shapes (K = d pairs, 3 x 1 024 columns): whole and ragged 256-row tiles, one and several N-tiles, an odd step count
+X3K16_SHAPES = [(2, 21, 8, 544, 3072, 1, 1, 0, False, False), (1, 1, 300, 256, 768, 1, 1, 0, False, False), (3, 9, 7, 96, 256, 1, 1, 0, False, False),
+                (16, 21, 16, 544, 3072, 1, 1, 0, False, False)]
+
+
+@pytest.mark.parametrize("shape", X3K16_SHAPES)
+def test_split_pair_gemm_large_tiles_are_bit_identical(shape):
+    """gemm_x3k16_f16 (256 x 256 tiles, k-steps of 16 channels on a four-stage ring: what the projections run on at large row counts)
+    against conv_igemm's fused split loop (what they run on otherwise): the same per-element sequence of 32x32x16 MFMAs, the same
+    bits -- which is what lets the launcher choose by size -- and torch fp64 at fp32-grade error."""
+    from handmvnet_amd import _lib
+    lib = _lib.load()
+    N, H, W, Cin, Cout, k, stride, pad, use_res, relu = shape
+    x, w, b, res, ref = _conv_case(shape)
+    dev = torch.device("cuda:0")
+    xin = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wc, bc = w.contiguous().numpy(), b.contiguous().numpy()
+    outs = []
+    try:
+        for mode in (1, 0):
+            assert lib.hmv_set_x3k16_mode(mode) == 0
+            out = torch.full((N, H, W, Cout), float("nan"), device=dev)
+            rc = lib.hmv_op_conv2d_ex(0, 2, xin.data_ptr(), N, H, W, Cin, wc.ctypes.data_as(ctypes.c_void_p), bc.ctypes.data_as(ctypes.c_void_p), Cout, 1, 1, 1, 0,
+                                      None, 0, out.data_ptr(), None)
+            assert rc == 0, lib.hmv_last_error(None)
+            outs.append(out.cpu())
+    finally:
+        lib.hmv_set_x3k16_mode(-1)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (outs[0] - outs[1]).abs().max()
+    got = outs[0].permute(0, 3, 1, 2).double()
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 3e-6
+
+
 @pytest.mark.parametrize("shape", HALF_SHAPES)
 def test_conv_kernel_fp16_vs_torch(shape):
     """... and with plain fp16 operands, fp32 accumulation: fp16-grade error."""

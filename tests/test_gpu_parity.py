@@ -502,6 +502,18 @@ def test_stream_kernel_is_bit_identical(shape):
         assert err < 1e-3, err
 
 
+def test_gemm8_refuses_a_padded_reduction():
+    """conv_gemm8's loop walks Kpad / 64 k-steps with no column mask, so a reduction that is not a whole number of 64-channel
+    steps (Cin = 160 -> Kpad = 192) must NOT reach it -- nor conv_m16's tiles (whole 32-channel steps of real channels only): with
+    kernel_sel = 2 ("the special kernels wherever the shape has one") such a conv falls back to conv_igemm, and the result is right."""
+    shape = (2, 16, 16, 160, 256, 1, 1, 0, False, True)
+    a, ka, (x, w, b, res, relu) = _run_conv_f16(shape, 2)
+    assert ka.startswith("conv_igemm_f16"), ka
+    ref = torch.nn.functional.conv2d(x.half().double().permute(0, 3, 1, 2), w.half().double(), b.double()).permute(0, 2, 3, 1).clamp_min(0)
+    assert torch.isfinite(a.float()).all()
+    assert (a.double() - ref).abs().max().item() / ref.abs().max().item() < 1e-3
+
+
 # 3x3 convs on the tall 512-pixel x 128-channel tiles (conv_ht.hip): 1 to 6 blocks per image, one and several N-tiles, 2 to 8
 # sub-chunks, ReLU on and off, more tiles than CUs
 HT_SHAPES = [(2, 16, 32, 64, 128, 3, 1, 1, False, True), (1, 32, 32, 128, 128, 3, 1, 1, False, False), (3, 48, 64, 256, 256, 3, 1, 1, False, True),

@@ -312,6 +312,179 @@ __global__ __launch_bounds__(512) void conv_ht_f16(const ConvParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_htp_f16: conv_ht_f16<M16> as a PERSISTENT kernel (round 4; VERDICT r3 lead: "request the next tile's first operands before the
+// epilogue").  One workgroup per CU (grid = 256) walks its tiles; the weight stages and the first halo image that a tile's last steps
+// would have fetched as dummies are the NEXT tile's -- its seven leading weight stages and chunk-0 halo are in flight while this tile's
+// last taps multiply and its epilogue stores -- so a tile starts at step 0 with the same static vmcnt counts and no prologue, and a CU
+// never idles between a workgroup's exit and the next one's first DMA round trip (prologue + epilogue were 7 of 61 us per tile).
+// Placement: XCD x owns the pixel blocks [x B, (x + 1) B), B = ceil(blocks / 8); its 32 workgroups are 32 / ntiles block slots x ntiles
+// channel tiles (a workgroup keeps its channel tile: weights pointer and bias registers are launch constants); the N-tiles of a block run
+// side by side on one XCD as before.  Same MFMA sequence per output as conv_ht_f16<true>: bit-identical (test_tall_tile_kernel).
+__global__ __launch_bounds__(512) void conv_htp_f16(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char tsm[];
+    char *wst = tsm + 2 * HT_IMG;
+    float *sbias = reinterpret_cast<float *>(tsm + HT_LDS);   // this workgroup's 128 initial accumulator values (bias / acc_scale)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;          // (blocks are dealt round-robin over the XCDs: speed only)
+    const int S = 32 / p.ntiles, nt = slot % p.ntiles, sidx = slot / p.ntiles;
+    const int Bx = (p.mtiles + 7) >> 3, blk_end = min((xcd + 1) * Bx, p.mtiles);
+    int blk = xcd * Bx + sidx;
+    if (blk >= blk_end) return;
+    const int tyn = p.H >> 4, txn = p.W >> 5, per_img = tyn * txn;
+    const _Float16 *zero16 = reinterpret_cast<const _Float16 *>(p.zero);
+    const int nchunk = p.Cin >> 5, nstep = 9 * nchunk;
+
+    // halo source pointer of DMA i of pixel block (n, by, bx) (nullptr: out of the image / past the halo -> zero page)
+    auto halo_ptr = [&](int n, int by, int bx, int i) -> const _Float16 * {
+        int t = tid;
+        asm volatile("" : "+v"(t));   // recomputed where it is used: nothing of it lives across the steps
+        const int L = 512 * i + t, hp = L >> 2, hy = hp / HT_HW, hx = hp - hy * HT_HW;
+        const int iy = by * 16 - 1 + hy, ix = bx * 32 - 1 + hx;
+        const bool ok = hp < HT_HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        return ok ? reinterpret_cast<const _Float16 *>(p.in) + ((size_t)(n * p.H + iy) * p.W + ix) * p.lda + 8 * ((L & 3) ^ ht_pkey<true>(hx)) : nullptr;
+    };
+    int bn = blk / per_img, by = (blk - bn * per_img) / txn, bx = blk - bn * per_img - by * txn;   // this tile's block (uniform)
+    const _Float16 *hcur[HT_HP];
+#pragma unroll
+    for (int i = 0; i < HT_HP; ++i) hcur[i] = halo_ptr(bn, by, bx, i);
+    const _Float16 *wsrc = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(nt * 128 + (tid >> 2)) * p.ldw + 8 * ((tid & 3) ^ ht_wkey<true>(tid >> 2));
+
+    if (tid < 128) sbias[tid] = p.bias[nt * 128 + tid] * (1.f / p.acc_scale);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the bias loads are not counted by the schedule below)
+
+    const int wrow = wn * 64 + 8 * (l15 >> 2) + (l15 & 3), wsw = ht_wkey<true>(wrow);
+    int poff[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) poff[dx][j] = ((4 * wm) * HT_HW + 16 * j + l15) * 64 + (kg ^ ht_pkey<true>(16 * j + l15 + dx)) * 16;
+
+    int gs = 0, gc = 0;   // running step / chunk counters: LDS slots are (gs & 7) and (gc & 1) across tiles
+    auto issue_wsrc = [&](const _Float16 *src, int g) {
+        asm volatile("" : "+v"(src));
+        HMV_TGLDS16(src, wst + (g & (HT_NWS - 1)) * HT_WST + wave * 1024);
+    };
+    auto issue_hsrc = [&](const _Float16 *src, int c, int i) {
+        asm volatile("" : "+v"(src));
+        HMV_TGLDS16(src, tsm + (c & 1) * HT_IMG + i * 8192 + wave * 1024);
+    };
+    // ---- prologue of the FIRST tile (as conv_ht_f16): its chunk-0 halo, then the steps "before the first"
+#pragma unroll
+    for (int i = 0; i < HT_HP; ++i) issue_hsrc(hcur[i] ? hcur[i] : zero16, 0, i);
+#pragma unroll
+    for (int f = -HT_LEAD; f < 0; ++f) {
+        issue_wsrc(wsrc + 32 * (f + HT_LEAD), f + HT_LEAD);
+        if (ht_h(f)) issue_hsrc(zero16, 1, 0);
+    }
+    ht_wait<8>();
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm >= 2) { asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+
+    const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    const int nb0 = nt * 128 + wn * 64;
+    const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 7) & ~7);
+    tf32x4 acc4[4][2][4];
+    tf16x8 fp[4][2], fw[2][2];
+    for (;;) {
+        const int nblk_ = blk + S;
+        const bool have_next = nblk_ < blk_end;
+        const int nn = nblk_ / per_img, nby = (nblk_ - nn * per_img) / txn, nbx = nblk_ - nn * per_img - nby * txn;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {   // channel 32 t + 8 kg + 4 e + u, cb = 2 t + e (as conv_ht_f16<true>)
+            const tf32x4 bq = *reinterpret_cast<const tf32x4 *>(sbias + wn * 64 + 32 * (cb >> 1) + 8 * kg + 4 * (cb & 1));
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc4[a][h][cb] = bq;
+        }
+        for (int c = 0; c < nchunk; ++c) {
+            const bool lastc = c == nchunk - 1;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int s = 9 * c + tap;
+                {   // fragment reads of this step
+                    const char *img_ = tsm + (gc & 1) * HT_IMG;
+                    const char *ws_ = wst + (gs & (HT_NWS - 1)) * HT_WST;
+#pragma unroll
+                    for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+                        for (int j_ = 0; j_ < 2; ++j_)
+                            fw[b_][j_] = *reinterpret_cast<const tf16x8 *>(ws_ + ((wrow + 32 * b_ + 4 * j_) * 4 + (kg ^ wsw)) * 16);
+#pragma unroll
+                    for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+                        for (int j_ = 0; j_ < 2; ++j_)
+                            fp[a_][j_] = *reinterpret_cast<const tf16x8 *>(img_ + poff[tap % 3][j_] + ((a_ + tap / 3) * HT_HW + tap % 3) * 64);
+                }
+                {   // the weight stage HT_LEAD steps ahead: this tile's, else the next tile's, else a dummy
+                    const int idx = s + HT_LEAD;
+                    const _Float16 *src = idx < nstep ? wsrc + 32 * idx : (have_next ? wsrc + 32 * (idx - nstep) : zero16);
+                    issue_wsrc(src, gs + HT_LEAD);
+                }
+                if (tap < HT_HP) {   // the next halo image: this tile's next sub-chunk, else the next tile's sub-chunk 0, else a dummy
+                    const _Float16 *src;
+                    if (!lastc) src = hcur[tap] ? hcur[tap] + 32 * (c + 1) : zero16;
+                    else {
+                        if (have_next) hcur[tap] = halo_ptr(nn, nby, nbx, tap);   // (this tile is done with pointer `tap`)
+                        src = (have_next && hcur[tap]) ? hcur[tap] : zero16;
+                    }
+                    issue_hsrc(src, gc + 1, tap);
+                }
+                switch (tap) {
+                    case 0: ht_wait<0>(); break; case 1: ht_wait<1>(); break; case 2: ht_wait<2>(); break;
+                    case 3: ht_wait<3>(); break; case 4: ht_wait<4>(); break; case 5: ht_wait<5>(); break;
+                    case 6: ht_wait<6>(); break; case 7: ht_wait<7>(); break; default: ht_wait<8>(); break;
+                }
+                asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+                    for (int h_ = 0; h_ < 2; ++h_)
+#pragma unroll
+                        for (int cb_ = 0; cb_ < 4; ++cb_)
+                            acc4[a_][h_][cb_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[cb_ >> 1][cb_ & 1], fp[a_][h_], acc4[a_][h_][cb_], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                ++gs;
+            }
+            ++gc;
+        }
+        // ---- epilogue of this tile (its stores are younger than the next tile's operands already in flight: the counted waits of the
+        // next steps then also retire the oldest of them -- conservative, never wrong)
+        {
+            const int n = bn;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const size_t pix = (size_t)(n * p.H + by * 16 + 4 * wm + a) * p.W + bx * 32 + 16 * h + l15;
+                    _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + pix * p.ldc;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int col = nb0 + 32 * t + 8 * kg;
+                        tf16x8 hv;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc4[a][h][2 * t + (u >> 2)][u & 3] * p.acc_scale + 0.f, lo);
+                        if (col < cend) *reinterpret_cast<tf16x8 *>(orow + col) = hv;
+                    }
+                }
+        }
+        if (!have_next) break;
+        blk = nblk_; bn = nn; by = nby; bx = nbx;
+    }
+    if (wm < 2) { asm volatile("s_barrier" ::: "memory"); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ====================================================================== host side
 static int g_ht_mode = -1;   // -1: launch_conv's rule (enough tiles to fill the chip); 0 never, 1 always (op-level tests)
 void conv_ht_set_mode(int mode) { g_ht_mode = mode; }
@@ -320,6 +493,8 @@ int conv_ht_mode() { return g_ht_mode; }
 // A/B partner, hmv_op_conv2d_f16 kernel_sel 5 / 6).  A property of the BUILD, not of a launch: every batch size runs the same shape.
 static int g_ht_m16 = 1;
 void conv_ht_set_shape(int m16) { g_ht_m16 = m16; }
+static int g_ht_persist = 1;   // 1: the persistent form from two tiles per CU up; 0: never; 2: wherever it exists (op-level identity tests)
+void conv_ht_set_persistent(int on) { g_ht_persist = on; }
 int conv_ht_shape() { return g_ht_m16; }
 
 // shape rule (the engine asks it at weight-packing time and at launch: the same answer for every batch)
@@ -346,6 +521,18 @@ hipError_t launch_conv_ht(ConvParams p, hipStream_t s, const char **name) {
     }
     p.mtiles = p.N * (p.H >> 4) * (p.W >> 5);
     p.ntiles = p.Cout / 128;
+    // the persistent form (16x16x32 only: the engine's shape): from two tiles per CU up, channel tiles that divide an XCD's 32 workgroups
+    if (g_ht_m16 && g_ht_persist && ((long long)p.mtiles * p.ntiles >= 512 || g_ht_persist == 2) && (p.ntiles == 1 || p.ntiles == 2 || p.ntiles == 4)) {
+        static bool pconf[64] = {};
+        if (!pconf[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_htp_f16), hipFuncAttributeMaxDynamicSharedMemorySize, HT_LDS + 512);
+            if (e != hipSuccess) return e;
+            pconf[dev] = true;
+        }
+        if (name) *name = "conv_ht_f16<512x128,3x3,m16,persistent>";
+        hipLaunchKernelGGL(conv_htp_f16, dim3(256), dim3(512), HT_LDS + 512, s, p);
+        return hipGetLastError();
+    }
     if (g_ht_m16) {
         if (name) *name = "conv_ht_f16<512x128,3x3,m16>";
         hipLaunchKernelGGL(conv_ht_f16<true>, dim3(p.mtiles * p.ntiles), dim3(512), HT_LDS, s, p);

@@ -2355,10 +2355,11 @@ extern "C" int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int
                                  const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad,
                                  const float *residual, int32_t relu, void *out_f16, int32_t kernel_sel, const char **kernel_name,
                                  void *stream) {
-    if (kernel_sel < 0 || kernel_sel > 6) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0 .. 6"; return HMV_ERR_ARG; }
-    const int force = kernel_sel == 0 ? -1 : (kernel_sel == 2 ? 1 : 0);   // 3 .. 6 (tall-tile packing) keep the other special kernels out
-    conv_ht_set_mode((kernel_sel == 3 || kernel_sel == 5) ? 1 : ((kernel_sel == 4 || kernel_sel == 6) ? 0 : -1));
-    conv_ht_set_shape(kernel_sel >= 5 ? 0 : 1);
+    if (kernel_sel < 0 || kernel_sel > 7) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0 .. 7"; return HMV_ERR_ARG; }
+    const int force = kernel_sel == 0 ? -1 : (kernel_sel == 2 ? 1 : 0);   // 3 .. 7 (tall-tile packing) keep the other special kernels out
+    conv_ht_set_mode((kernel_sel == 3 || kernel_sel == 5 || kernel_sel == 7) ? 1 : ((kernel_sel == 4 || kernel_sel == 6) ? 0 : -1));
+    conv_ht_set_shape((kernel_sel == 5 || kernel_sel == 6) ? 0 : 1);
+    conv_ht_set_persistent(kernel_sel == 7 ? 2 : (kernel_sel == 3 ? 0 : 1));
     conv_stream_set_mode(force);
     conv_gemm8_set_mode(force);
     conv_hs_set_mode(force);
@@ -2366,6 +2367,7 @@ extern "C" int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int
                                  residual, relu, out_f16, true, kernel_name, stream, kernel_sel >= 3);   // (3 .. 6: the tall-tile packing)
     conv_ht_set_mode(-1);
     conv_ht_set_shape(1);
+    conv_ht_set_persistent(1);
     conv_stream_set_mode(-1);
     conv_gemm8_set_mode(-1);
     conv_hs_set_mode(-1);

@@ -194,6 +194,7 @@ void conv_ht_set_mode(int mode);   // -1 launch_conv's rule, 0 never (the c32 ti
 int conv_ht_mode();
 void conv_ht_set_shape(int m16);   // MFMA shape of the tall-tile layers: 1 = 16x16x32 (the engine's, round 4), 0 = 32x32x16 (the A/B partner)
 int conv_ht_shape();
+void conv_ht_set_persistent(int on);   // 1 (default): the persistent form from two tiles per CU up; 0: one workgroup per tile; 2: wherever it exists (tests)
 // conv_m16.hip: the small-launch companion of the 16x16x32-MFMA kernels (64 x 64 / 128 x 128 tiles; 3x3 in conv_ht's K order, plain
 // 1x1): same bits as conv_ht<..., m16>, so a layer's result does not depend on which of the two its batch size selects
 bool conv_m16_supported(const ConvParams &p);

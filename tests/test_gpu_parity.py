@@ -518,6 +518,8 @@ def test_gemm8_refuses_a_padded_reduction():
 # sub-chunks, ReLU on and off, more tiles than CUs
 HT_SHAPES = [(2, 16, 32, 64, 128, 3, 1, 1, False, True), (1, 32, 32, 128, 128, 3, 1, 1, False, False), (3, 48, 64, 256, 256, 3, 1, 1, False, True),
              (5, 32, 32, 256, 384, 3, 1, 1, False, True), (72, 32, 32, 128, 256, 3, 1, 1, False, True)]
+# ... and launches of two and more tiles per CU (the persistent form's own size: 4-5 and 2-3 tiles per workgroup, ragged per XCD)
+HTP_SHAPES = HT_SHAPES + [(67, 32, 64, 64, 512, 3, 1, 1, False, True), (150, 32, 32, 128, 256, 3, 1, 1, False, False)]
 
 
 @pytest.mark.parametrize("shape", HT_SHAPES)
@@ -560,6 +562,20 @@ def test_tall_tile_kernel(shape):
                                    bc.ctypes.data_as(ctypes.c_void_p), one[4], 3, 3, 1, 1, None, int(relu), out.data_ptr(), 4, None, None)   # on the small-launch tiles
         assert rc == 0, lib.hmv_last_error(None)
         assert torch.equal(out.cpu()[0].view(torch.int16), a[0].view(torch.int16))
+
+
+@pytest.mark.parametrize("shape", HTP_SHAPES)
+def test_tall_tile_kernel_persistent_form(shape):
+    """conv_ht's persistent form (round 4: one workgroup per CU walks its tiles, the next tile's weight stages and first halo image
+    in flight under the last taps and the epilogue of this one) against one workgroup per tile: same MFMA sequence per output, so the
+    same bits at every size -- the launcher may pick between them by tile count (>= 2 per CU) without a sample's result depending on
+    its batch.  kernel_sel 7 forces the persistent form on small launches too (idle workgroups, one tile per workgroup, ragged XCDs)."""
+    a, ka, _ = _run_conv_f16(shape, 3)
+    e, ke, _ = _run_conv_f16(shape, 7)
+    assert ka == "conv_ht_f16<512x128,3x3,m16>", ka
+    assert ke == ("conv_ht_f16<512x128,3x3,m16,persistent>" if shape[4] // 128 in (1, 2, 4) else ka), ke
+    assert torch.isfinite(a.float()).all()
+    assert torch.equal(a.view(torch.int16), e.view(torch.int16)), (a.float() - e.float()).abs().max()
 
 
 # shapes that give conv_m16 its 128 x 128 tiles (>= 256 of them; a tall layer's M is always a multiple of 512, so there is no ragged M here)

@@ -305,6 +305,220 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8_f16(const ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// conv_gemm8p_f16: conv_gemm8_f16<DUAL, M16 = true> as a PERSISTENT kernel (round 4, after conv_htp_f16).  One workgroup per CU (grid
+// = 256) walks its tiles.  The half-tiles that a tile's last two k-steps would have requested as dummies are the NEXT tile's first seven
+// -- in the prologue's own order, A0 W0 W1 A1 of step 0, A0 W0 W1 of step 1 -- so the next tile starts at phase 1 with its operands
+// landed or in flight (the one-workgroup-per-tile kernel pays an HBM round trip of 2-4 us per 30-40 us tile there), and its epilogue
+// stores drain under the next tile's first phases.  Placement as conv_htp_f16: XCD x owns the pixel tiles [x B, (x + 1) B), its 32
+// workgroups are 32 / ntiles tile slots x ntiles channel tiles (a workgroup keeps its channel tile).  The epilogue's stores are younger
+// than the DMAs in flight, so the counted waits of the next phases also retire stores: conservative, never wrong.  Same MFMA sequence
+// per output as conv_gemm8_f16<DUAL, true>: bit-identical (test_gemm8_persistent_form).
+template <bool DUAL>
+__global__ __launch_bounds__(512) void conv_gemm8p_f16(const ConvParams p) {
+    constexpr int HT = 128 * 64;   // halfs per half-tile
+    extern __shared__ __attribute__((aligned(16))) _Float16 gsm[];   // [2 k-steps][A0, A1, B0, B1][128][64], then 256 floats of bias
+    float *sbias = reinterpret_cast<float *>(gsm + 2 * 4 * HT);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int S = 32 / p.ntiles, nt = slot % p.ntiles, sidx = slot / p.ntiles;
+    const int Bx = (p.mtiles + 7) >> 3, mt_end = min((xcd + 1) * Bx, p.mtiles);
+    int mt = xcd * Bx + sidx;
+    if (mt >= mt_end) return;
+    const _Float16 *zero = reinterpret_cast<const _Float16 *>(p.zero);
+    const int nk = p.Kpad >> 6;
+
+    const int kqs = (tid & 7) ^ ((tid >> 4) & 7);
+    // element offsets of the four pixel rows a thread moves ([half h][pass i]) in pixel tile mt_ (-1: past M -> zero page)
+    auto rows_of = [&](int mt_, int (&o1)[2][2], int (&o2)[2][2]) {
+        int t = tid;
+        asm volatile("" : "+v"(t));   // recomputed per tile: nothing of it lives across the phases
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hr = (t >> 3) + 64 * i;
+                const int m = mt_ * 256 + (hr >> 6) * 128 + (2 * h + ((hr >> 5) & 1)) * 32 + (hr & 31);
+                o1[h][i] = m < p.M ? m * p.lda + 8 * kqs : -1;
+                o2[h][i] = -1;
+                if constexpr (DUAL) {
+                    if (m < p.M) {
+                        const int hw = p.Ho * p.Wo, n = m / hw, rem = m - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                        o2[h][i] = ((n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.lda2 + 8 * kqs;
+                    }
+                }
+            }
+    };
+    int aoff[2][2], aoff2[2][2], noff[2][2] = {{-1, -1}, {-1, -1}}, noff2[2][2] = {{-1, -1}, {-1, -1}};   // this tile's rows, the next tile's
+    rows_of(mt, aoff, aoff2);
+    const _Float16 *wsrc[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hr = (tid >> 3) + 64 * i;
+            const int line = hr & 31, ch = 8 * ((line & 15) >> 2) + 4 * (line >> 4) + (line & 3);
+            wsrc[h][i] = reinterpret_cast<const _Float16 *>(p.wgt) + (size_t)(nt * 256 + (hr >> 5) * 64 + h * 32 + ch) * p.ldw + 8 * kqs;
+        }
+    const _Float16 *Ain = reinterpret_cast<const _Float16 *>(p.in), *Ain2 = reinterpret_cast<const _Float16 *>(p.in2);
+
+    int par = 0;            // LDS buffer of this tile's k-step 0 (k-steps alternate buffers across tiles)
+    bool have_next = false;
+    // half-tile `which` of k-step t of THIS tile; t >= nk: k-step t - nk of the next tile (none: dummies from the zero page)
+    auto stage = [&](int t, int which) {
+        _Float16 *dst = gsm + (((t + par) & 1) * 4 + which) * HT + wave * 8 * 64;
+        const bool nxt = t >= nk;
+        const bool live = !nxt || have_next;
+        const int k0 = (nxt ? t - nk : t) << 6;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const _Float16 *src = zero;
+            if (which < 2) {
+                const int o1 = nxt ? noff[which][i] : aoff[which][i];
+                if constexpr (DUAL) {
+                    const int o2 = nxt ? noff2[which][i] : aoff2[which][i];
+                    if (live && k0 >= p.ksplit) { if (o2 >= 0) src = Ain2 + (size_t)o2 + (k0 - p.ksplit); }
+                    else if (live && o1 >= 0) src = Ain + (size_t)o1 + k0;
+                } else {
+                    if (live && o1 >= 0) src = Ain + (size_t)o1 + k0;
+                }
+            } else if (live) {
+                src = wsrc[which - 2][i] + k0;
+            }
+            asm volatile("" : "+v"(src));   // ONE DMA instruction per schedule entry
+            HMV_GGLDS16(src, dst + i * 64 * 64);
+        }
+    };
+
+    if (tid < 256) sbias[tid] = p.bias[nt * 256 + tid] * (1.f / p.acc_scale);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias loads: the counted waits below see DMAs (and a tile's stores) only
+
+    const int fsw = (l15 >> 1) & 7;
+    const int prow = (wm * 64 + l15) * 64, wrow = (wn * 32 + l15) * 64;
+    gf16x8 fa[2][4], fb0[4], fb1[4];   // fa[a][2 s + g], fb[2 e + g]
+    gf32x4 acc4[4][2][2][2];
+#define G8P_READ_P(t, h)                                                                                    \
+    _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                    \
+            fa[a_][q_] = *reinterpret_cast<const gf16x8 *>(gsm + ((((t) + par) & 1) * 4 + (h)) * HT + prow + (a_ * 32 + (q_ >> 1) * 16) * 64 + (((4 * (q_ & 1) + kg) ^ fsw) * 8));
+#define G8P_READ_W(t, h, FB)                                                                                \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                        \
+        FB[q_] = *reinterpret_cast<const gf16x8 *>(gsm + ((((t) + par) & 1) * 4 + 2 + (h)) * HT + wrow + (q_ >> 1) * 16 * 64 + (((4 * (q_ & 1) + kg) ^ fsw) * 8));
+#define G8P_MFMA(A0, B, FB)                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_)                                                        \
+        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                                    \
+            _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                \
+                _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_)                                            \
+                    acc4[(A0) + a_][s_][B][e_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FB[2 * e_ + g_], fa[a_][2 * s_ + g_], acc4[(A0) + a_][s_][B][e_], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+#define G8P_BAR()                                                                                           \
+    asm volatile("s_barrier" ::: "memory");                                                                 \
+    __builtin_amdgcn_sched_barrier(0)
+#define G8P_WAIT10() asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory")
+#define G8P_WAITLDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+    // ---- prologue of the FIRST tile (conv_gemm8_f16's)
+    stage(0, 0);
+    stage(0, 2);
+    stage(0, 3);
+    stage(0, 1);
+    stage(1, 0);
+    stage(1, 2);
+    stage(1, 3);
+    G8P_WAIT10();
+    G8P_BAR();
+    if (wm == 1) G8P_BAR();   // the second wave half runs one barrier behind the first from here on
+
+    const float lo = (p.act == ACT_RELU) ? 0.f : -INFINITY;
+    const int nb0 = nt * 256 + wn * 64;
+    const int cend = (p.fill || p.Cout + 3 >= p.ldc) ? p.ldc : ((p.Cout + 7) & ~7);
+    for (;;) {
+        const int mt_next = mt + S;
+        have_next = mt_next < mt_end;
+        if (have_next) rows_of(mt_next, noff, noff2);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {   // register r of block (b, e) = channel 32 b + 8 kg + 4 e + r (as conv_gemm8_f16<., true>)
+                const gf32x4 bq = *reinterpret_cast<const gf32x4 *>(sbias + wn * 64 + 32 * b + 8 * kg + 4 * e);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) acc4[a][sb][b][e] = bq;
+            }
+        for (int t = 0; t < nk; ++t) {
+            // phase 1
+            G8P_READ_W(t, 0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            G8P_READ_P(t, 0);
+            stage(t + 1, 1);
+            G8P_WAIT10();
+            G8P_BAR();
+            G8P_MFMA(0, 0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            G8P_BAR();
+            // phase 2
+            G8P_READ_W(t, 1, fb1);
+            stage(t + 2, 0);
+            G8P_WAIT10();
+            G8P_BAR();
+            G8P_MFMA(0, 1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            G8P_BAR();
+            // phase 3
+            G8P_READ_P(t, 1);
+            stage(t + 2, 2);
+            G8P_WAITLDS();
+            G8P_BAR();
+            G8P_MFMA(2, 1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            G8P_BAR();
+            // phase 4
+            stage(t + 2, 3);
+            G8P_WAIT10();
+            G8P_BAR();
+            G8P_MFMA(2, 0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            G8P_BAR();
+        }
+        // ---- epilogue of this tile (conv_gemm8_f16<., true>'s)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const int m = mt * 256 + wm * 128 + 32 * a + 16 * sb + l15;
+                _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + (size_t)m * p.ldc;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int col = nb0 + 32 * b + 8 * kg;
+                    gf16x8 hv;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) hv[u] = (_Float16)fmaxf(acc4[a][sb][b][u >> 2][u & 3] * p.acc_scale + 0.f, lo);
+                    if (m < p.M && col < cend) *reinterpret_cast<gf16x8 *>(orow + col) = hv;
+                }
+            }
+        if (!have_next) break;
+        mt = mt_next;
+        par = (par + nk) & 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { aoff[h][i] = noff[h][i]; aoff2[h][i] = noff2[h][i]; }
+    }
+    if (wm == 0) G8P_BAR();   // the first half waits for the second: barrier counts match
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef G8P_READ_P
+#undef G8P_READ_W
+#undef G8P_MFMA
+#undef G8P_BAR
+#undef G8P_WAIT10
+#undef G8P_WAITLDS
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // conv_gemm8r_f16: the same tile on 32-element k-steps with the two operand streams on SEPARATE waves.
 //
 // Vector-memory returns are in order per wave.  A wave that requests both operand tiles queues its weight lines -- L2 hits, back in
@@ -485,6 +699,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8r_f16(const ConvParams p) {
 // ====================================================================== host side
 static int g_gemm8_mode = -1;   // -1: the launcher's rule (HMV_NO_GEMM8=1 disables it); 0 never; 1 whenever supported (op-level tests)
 void conv_gemm8_set_mode(int mode) { g_gemm8_mode = mode; }
+static int g_gemm8_persist = 1;   // 1: the persistent form from two tiles per CU up; 0: never; 2: wherever it exists (op-level identity tests)
+void conv_gemm8_set_persistent(int on) { g_gemm8_persist = on; }
 
 bool conv_gemm8_supported(const ConvParams &p) {
     static int off = -1;   // development knob: HMV_NO_GEMM8=1 keeps these convs on conv_igemm (A/B runs)
@@ -525,6 +741,20 @@ hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name) {
     }
     p.mtiles = (p.M + 255) / 256;
     p.ntiles = (p.Cout + 255) / 256;
+    // the persistent form (16x16x32 only): from two tiles per CU up, channel-tile counts that divide an XCD's 32 workgroups
+    if (p.m16 && g_gemm8_persist && ((long long)p.mtiles * p.ntiles >= 512 || g_gemm8_persist == 2) && (p.ntiles == 1 || p.ntiles == 2 || p.ntiles == 4)) {
+        static bool pconf[64] = {};
+        if (!pconf[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8p_f16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm8p_f16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 1024);
+            if (e != hipSuccess) return e;
+            pconf[dev] = true;
+        }
+        if (name) *name = p.in2 ? "conv_gemm8_f16<256x256,1x1,dual,m16,persistent>" : "conv_gemm8_f16<256x256,1x1,m16,persistent>";
+        if (p.in2) hipLaunchKernelGGL(conv_gemm8p_f16<true>, dim3(256), dim3(512), lds + 1024, s, p);
+        else hipLaunchKernelGGL(conv_gemm8p_f16<false>, dim3(256), dim3(512), lds + 1024, s, p);
+        return hipGetLastError();
+    }
     if (p.m16) {   // the layer multiplies on the 16x16x32 MFMA at every batch size (conv_m16_rule: by shape)
         if (name) *name = p.in2 ? "conv_gemm8_f16<256x256,1x1,dual,m16>" : "conv_gemm8_f16<256x256,1x1,m16>";
         if (p.in2) hipLaunchKernelGGL((conv_gemm8_f16<true, true>), dim3(p.mtiles * p.ntiles), dim3(512), lds, s, p);

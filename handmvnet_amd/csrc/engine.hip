@@ -2355,8 +2355,9 @@ extern "C" int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int
                                  const float *bias_host, int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t pad,
                                  const float *residual, int32_t relu, void *out_f16, int32_t kernel_sel, const char **kernel_name,
                                  void *stream) {
-    if (kernel_sel < 0 || kernel_sel > 7) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0 .. 7"; return HMV_ERR_ARG; }
-    const int force = kernel_sel == 0 ? -1 : (kernel_sel == 2 ? 1 : 0);   // 3 .. 7 (tall-tile packing) keep the other special kernels out
+    if (kernel_sel < 0 || kernel_sel > 8) { g_create_err = "hmv_op_conv2d_f16: kernel_sel must be 0 .. 8"; return HMV_ERR_ARG; }
+    const int force = kernel_sel == 0 ? -1 : ((kernel_sel == 2 || kernel_sel == 8) ? 1 : 0);   // 3 .. 7 (tall-tile packing) keep the other special kernels out
+    conv_gemm8_set_persistent(kernel_sel == 8 ? 2 : (kernel_sel == 2 ? 0 : 1));
     conv_ht_set_mode((kernel_sel == 3 || kernel_sel == 5 || kernel_sel == 7) ? 1 : ((kernel_sel == 4 || kernel_sel == 6) ? 0 : -1));
     conv_ht_set_shape((kernel_sel == 5 || kernel_sel == 6) ? 0 : 1);
     conv_ht_set_persistent(kernel_sel == 7 ? 2 : (kernel_sel == 3 ? 0 : 1));
@@ -2364,10 +2365,11 @@ extern "C" int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int
     conv_gemm8_set_mode(force);
     conv_hs_set_mode(force);
     const int rc = op_conv2d_any("hmv_op_conv2d_f16", device, HMV_F16, in, N, H, W, Cin, w_oihw, bias_host, Cout, R, S, stride, pad,
-                                 residual, relu, out_f16, true, kernel_name, stream, kernel_sel >= 3);   // (3 .. 6: the tall-tile packing)
+                                 residual, relu, out_f16, true, kernel_name, stream, kernel_sel >= 3 && kernel_sel <= 7);   // (3 .. 7: the tall-tile packing)
     conv_ht_set_mode(-1);
     conv_ht_set_shape(1);
     conv_ht_set_persistent(1);
+    conv_gemm8_set_persistent(1);
     conv_stream_set_mode(-1);
     conv_gemm8_set_mode(-1);
     conv_hs_set_mode(-1);

@@ -175,6 +175,7 @@ hipError_t launch_cheb_mix(const float *y, int ldy, int B, int co, const float *
 bool conv_gemm8_supported(const ConvParams &p);
 void conv_gemm8_set_mode(int mode);   // -1 launcher's rule, 0 never, 1 whenever supported (op-level tests)
 hipError_t launch_conv_gemm8(ConvParams p, hipStream_t s, const char **name);
+void conv_gemm8_set_persistent(int on);   // 1 (default): the persistent form from two tiles per CU up; 0: one workgroup per tile; 2: wherever it exists (tests)
 
 // conv_hs.hip: persistent weight-stationary R x S convolution for few-channel fp16 layers (3x3 64 -> 64; the 4x4 space-to-depth
 // stem): weights in registers, one halo image per 16 x 16 output block.  Bit-identical to conv_igemm's result.

@@ -205,7 +205,8 @@ int hmv_op_conv2d_sel(int32_t device, const float *in, int32_t N, int32_t H, int
  * 32-channel-chunk tiles: the partner of the MFMA-shape A/B of round 4, not used by the engine; 5 and 6 agree bit for bit with
  * each other, and with 3 / 4 to the last fp16 bit of a few outputs); 7 = as 3 on conv_ht's PERSISTENT form (one workgroup per CU walks
  * its tiles with the next tile's operands in flight; what a launch of two or more tiles per CU runs on; 3 is one workgroup per tile
- * whatever the size; same bits; channel-tile counts other than 1, 2, 4 have no persistent form and run as 3).  *kernel_name (optional) receives the family that ran.
+ * whatever the size; same bits; channel-tile counts other than 1, 2, 4 have no persistent form and run as 3); 8 = as 2 with conv_gemm8's
+ * PERSISTENT form wherever it exists (2 is one workgroup per tile whatever the size; same bits).  *kernel_name (optional) receives the family that ran.
  * TEST HOOKS: the hmv_op_* entries with a kernel_sel argument switch PROCESS-GLOBAL kernel-selection state for the duration of the
  * call.  They are single-threaded test / probe entries: never call one concurrently with any other hmv_* call of the process
  * (an hmv_forward running on another thread would see the forced selection). */

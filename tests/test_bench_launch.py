@@ -92,6 +92,8 @@ def test_pmc_summary_names_the_round3_kernels_like_the_engine_does():
     assert ps.family("void hmv::conv_gemm8_f16<true, true>(hmv::ConvParams)") == "conv_gemm8_f16<256x256,1x1,dual,m16>"
     assert ps.family("void hmv::conv_ht_f16<true>(hmv::ConvParams)") == "conv_ht_f16<512x128,3x3,m16>"
     assert ps.family("_ZN3hmv11conv_ht_f16ILb0EEEvNS_10ConvParamsE.kd") == "conv_ht_f16<512x128,3x3>"
+    assert ps.family("void hmv::conv_gemm8p_f16<true>(hmv::ConvParams)") == "conv_gemm8_f16<256x256,1x1,dual,m16,persistent>"
+    assert ps.family("_ZN3hmv15conv_gemm8p_f16ILb0EEEvNS_10ConvParamsE.kd") == "conv_gemm8_f16<256x256,1x1,m16,persistent>"
     assert ps.family("hmv::conv_htp_f16(hmv::ConvParams)") == "conv_ht_f16<512x128,3x3,m16,persistent>"
     assert ps.family("_ZN3hmv12conv_htp_f16ENS_10ConvParamsE.kd") == "conv_ht_f16<512x128,3x3,m16,persistent>"
     assert ps.family("void hmv::conv_m16_f16<64, 64, true, false>(hmv::ConvParams)") == "conv_m16_f16<64x64,taps,c32>"

@@ -564,6 +564,25 @@ def test_tall_tile_kernel(shape):
         assert torch.equal(out.cpu()[0].view(torch.int16), a[0].view(torch.int16))
 
 
+# ... conv_gemm8's: the op-level shapes (idle workgroups, ragged pixel tails, one and two channel tiles) and launches of 2-5 tiles per CU
+G8P_SHAPES = GEMM8_SHAPES + [(136, 32, 32, 512, 512, 1, 1, 0, False, True), (131, 17, 19, 1024, 256, 1, 1, 0, False, False),
+                             (70, 32, 32, 256, 1024, 1, 1, 0, False, True)]
+
+
+@pytest.mark.parametrize("shape", G8P_SHAPES)
+def test_gemm8_persistent_form(shape):
+    """conv_gemm8's persistent form (round 4: one workgroup per CU walks its tiles; the half-tiles a tile's last two k-steps used to
+    request as dummies are the next tile's first seven) against one workgroup per tile: same bits at every size, so the launcher picks
+    between them by tile count.  kernel_sel 8 forces the persistent form on small launches too (channel-tile counts other than
+    1, 2, 4 have none and run as kernel_sel 2)."""
+    a, ka, _ = _run_conv_f16(shape, 2)
+    e, ke, _ = _run_conv_f16(shape, 8)
+    assert ka == "conv_gemm8_f16<256x256,1x1,m16>", ka
+    assert ke == ("conv_gemm8_f16<256x256,1x1,m16,persistent>" if (shape[4] + 255) // 256 in (1, 2, 4) else ka), ke
+    assert torch.isfinite(a.float()).all()
+    assert torch.equal(a.view(torch.int16), e.view(torch.int16)), (a.float() - e.float()).abs().max()
+
+
 @pytest.mark.parametrize("shape", HTP_SHAPES)
 def test_tall_tile_kernel_persistent_form(shape):
     """conv_ht's persistent form (round 4: one workgroup per CU walks its tiles, the next tile's weight stages and first halo image

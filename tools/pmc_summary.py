@@ -66,6 +66,9 @@ def family(name: str) -> str:
     if re.match(r"(?:void )?(?:hmv::)?conv_hs_stem_f32<", name):
         return "conv_hs_stem_f32<4x4,12->64>"
     # round 4: conv_ht_f16<M16>, conv_gemm8_f16<DUAL, M16>, conv_m16_f16<BM, BN, TAPS, DUAL>, gemm_x3_f16<BM, BN, WGM, WGN> (demangled or not)
+    m = re.match(r"(?:void )?(?:hmv::)?conv_gemm8p_f16<(true|false)>", name) or re.match(r"_ZN3hmv15conv_gemm8p_f16ILb([01])EE", name)
+    if m:
+        return "conv_gemm8_f16<256x256,1x1," + ("dual," if m.group(1) in ("true", "1") else "") + "m16,persistent>"
     if re.match(r"(?:void )?(?:hmv::)?conv_htp_f16\(", name) or name.startswith("_ZN3hmv12conv_htp_f16E"):
         return "conv_ht_f16<512x128,3x3,m16,persistent>"
     m = re.match(r"(?:void )?(?:hmv::)?conv_ht_f16<(true|false)>", name) or re.match(r"_ZN3hmv11conv_ht_f16ILb([01])EE", name)

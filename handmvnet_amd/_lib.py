@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("HMV_LIB") or os.path.join(_HERE, "libhandmv.so")   # 
 SYMBOLS = ["hmv_create", "hmv_set_tensor", "hmv_finalize_weights", "hmv_workspace_bytes", "hmv_reserve", "hmv_forward",
            "hmv_last_error", "hmv_destroy", "hmv_set_capture", "hmv_read_stage", "hmv_set_profiling", "hmv_profile_count",
            "hmv_profile_get", "hmv_op_conv2d", "hmv_op_conv2d_ex", "hmv_op_conv2d_f16", "hmv_op_conv2d_sel", "hmv_op_conv2d_rd", "hmv_op_attention", "hmv_op_attention_lq", "hmv_bench_conv", "hmv_pose_metrics", "hmv_forward_frames",
-           "hmv_op_prepare_frames", "hmv_set_graphs", "hmv_graph_stats", "hmv_version", "hmv_tile_rule", "hmv_profile_get_bytes", "hmv_poison_workspace", "hmv_launch_count", "hmv_set_tail_fusion", "hmv_set_chain_fusion", "hmv_set_x3k16_mode"]
+           "hmv_op_prepare_frames", "hmv_set_graphs", "hmv_graph_stats", "hmv_version", "hmv_tile_rule", "hmv_profile_get_bytes", "hmv_poison_workspace", "hmv_launch_count", "hmv_set_tail_fusion", "hmv_set_chain_fusion", "hmv_set_hr_fusion", "hmv_set_x3k16_mode"]
 
 HMV_OK = 0
 
@@ -52,6 +52,7 @@ def load() -> ctypes.CDLL:
     lib.hmv_launch_count.argtypes = [vp]
     lib.hmv_set_tail_fusion.argtypes = [vp, ci]
     lib.hmv_set_chain_fusion.argtypes = [vp, ci]
+    lib.hmv_set_hr_fusion.argtypes = [vp, ci]
     lib.hmv_forward.argtypes = [vp, ci, fp, fp, fp, fp, fp, fp, vp]
     lib.hmv_last_error.argtypes = [vp]
     lib.hmv_last_error.restype = ctypes.c_char_p

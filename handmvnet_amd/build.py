@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libhandmv.so")
-SOURCES = ["conv_igemm.hip", "conv_stream.hip", "conv_gemm8.hip", "conv_hs.hip", "conv_ht.hip", "conv_m16.hip", "gemm_x3.hip", "conv_rds.hip", "misc_kernels.hip", "fusion_kernels.hip", "engine.hip", "metrics.hip"]
+SOURCES = ["conv_igemm.hip", "conv_stream.hip", "conv_gemm8.hip", "conv_hs.hip", "conv_ht.hip", "conv_m16.hip", "gemm_x3.hip", "conv_rds.hip", "misc_kernels.hip", "fusion_kernels.hip", "hr_fuse.hip", "engine.hip", "metrics.hip"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(os.path.dirname(HERE), "include", "handmv.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 

@@ -69,6 +69,7 @@ struct Block {
 struct HrModule {
     Layer br[4][4][2];             // [branch][block][conv1 | conv2]
     std::vector<Layer> fuse[4][4]; // [i][j]: j > i one 1x1 conv; j < i a chain of (i - j) stride-2 3x3 convs
+    Layer fup[4][4];               // fp16 mode: the j > i 1x1 convs once more as fp32 [Cout][Cin] for hr_fuse.hip (the fp32 mode reads fuse[i][j][0])
 };
 struct HrNet {
     Layer conv1, conv2;            // stem: two 3x3 stride-2 convs
@@ -210,6 +211,7 @@ struct hmv_engine {
     // fused tail kernels (fusion_kernels.hip); HMV_NO_FFFUSE=1 / HMV_NO_CHEBFUSE=1 in the environment or hmv_set_tail_fusion(h, 0)
     // select the launch-per-op path (A/B runs, the equivalence test).  Part of the workspace plan: changing them re-plans.
     bool ff_fuse = true, cheb_fuse = true;
+    bool hr_fuse = true;      // HRNet: the up-sampling terms of a fuse layer as one launch (hr_fuse.hip); hmv_set_hr_fusion(h, 0): one launch per term
     bool chain_fuse = true;   // conv3 -> next block's conv1 in one launch (conv_stream.hip chain); hmv_set_chain_fusion(h, 0) / HMV_NO_CHAIN=1
     std::vector<GraphEntry> gcache;
     std::vector<GraphKey> gseen;     // buffer sets run eagerly once and not captured yet (callers often alternate between a few)
@@ -665,6 +667,8 @@ int hmv_finalize_weights(hmv_handle h) {
                             Layer l;
                             L.conv(l, fl, fp + ".0.weight", "", fp + ".1", hr.ch[i], hr.ch[j], 1, 1, cpad(hr.ch[j]), h16);
                             M.fuse[i][j].push_back(l);
+                            if (h16 && !L.split && nbr - 1 - i >= 2)   // (only branches with two or more up-sampling terms run fused)
+                                L.conv(M.fup[i][j], fl, fp + ".0.weight", "", fp + ".1", hr.ch[i], hr.ch[j], 1, 1, cpad(hr.ch[j]), false);
                         } else if (j < i) {
                             for (int q = 0; q < i - j; ++q) {
                                 const int outc = (q == i - j - 1) ? hr.ch[i] : hr.ch[j];
@@ -1210,6 +1214,37 @@ struct Runner {
         }
     }
 
+    // the up-sampling terms of an HRNet fuse layer in one launch (hr_fuse.hip)
+    void hr_fuse_up(const HrFuseParams &p, const std::string &label) {
+        if (dry || rc != HMV_OK) return;
+        ProfRec *pr = nullptr;
+        if (h->profiling) {
+            if (h->prof_used == h->prof.size()) {
+                ProfRec r{};
+                check(hipEventCreate(&r.e0), "hipEventCreate");
+                check(hipEventCreate(&r.e1), "hipEventCreate");
+                h->prof.push_back(r);
+            }
+            pr = &h->prof[h->prof_used++];
+            pr->label = label;
+            const double eb = p.f16 ? 2.0 : 4.0;
+            pr->flops = 0.0;
+            pr->bytes = 2.0 * (double)p.N * p.H * p.W * p.C * eb;   // the map once in, once out
+            for (int q = 0; q < p.nsrc; ++q) {   // the products at the sources' own resolution
+                const HrFuseSrc &S = p.src[q];
+                pr->flops += 2.0 * (double)p.N * S.H * S.W * S.C * p.C;
+                pr->bytes += (double)p.N * S.H * S.W * S.C * eb + (double)S.C * p.C * 4.0;
+            }
+            check(hipEventRecord(pr->e0, s), "hipEventRecord");
+        }
+        check(launch_hr_fuse_up(p, s), label.c_str());
+        ++h->launches;
+        if (pr) {
+            pr->name = p.f16 ? "hr_fuse_up_f16" : "hr_fuse_up_f32";
+            check(hipEventRecord(pr->e1, s), "hipEventRecord");
+        }
+    }
+
     static int splitk_slices(const Layer &L, int rows) {
         static const bool no_splitk = HMV_DEV_ENV("HMV_NO_SPLITK") != nullptr;   // development knob (A/B runs)
         return (!no_splitk && !L.f16 && L.R == 1 && L.S == 1 && !L.plane && L.Kpad >= 1024 && L.Kpad % 128 == 0 &&
@@ -1444,8 +1479,21 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                     const int cpi = cpad(hr.ch[i]);
                     float *running = nullptr;
                     int nterm = 0;
+                    // two or more up-sampling terms (always the last of the sum): one launch for all of them (hr_fuse.hip)
+                    HrFuseParams fp{};
+                    bool fused = false;
+                    if (h->hr_fuse && !split && nbr - 1 - i >= 2) {
+                        fp.N = N; fp.H = hs[i]; fp.W = ws[i]; fp.C = hr.ch[i]; fp.ldc = cpi; fp.relu = 1; fp.f16 = h16 ? 1 : 0;
+                        for (int j = i + 1; j < nbr; ++j) {
+                            const Layer &l = h16 ? M.fup[i][j] : M.fuse[i][j][0];
+                            HrFuseSrc &S = fp.src[fp.nsrc++];
+                            S.w = l.w; S.bias = l.bias; S.C = hr.ch[j]; S.ld = cpad(hr.ch[j]); S.ldw = l.Kpad; S.shift = j - i; S.H = hs[j]; S.W = ws[j];
+                        }
+                        fused = fp.src[0].w != nullptr && hr_fuse_up_plan(fp);
+                    }
                     for (int j = 0; j < nbr; ++j) {
                         if (j == i) continue;
+                        if (fused && j > i) continue;
                         const bool first = nterm == 0, last = nterm == nbr - 2;
                         const float *res = first ? xs[i] : running;
                         const int act = last ? ACT_RELU : ACT_NONE;
@@ -1477,6 +1525,15 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                         if (!first) R.release(running);
                         running = o;
                         ++nterm;
+                    }
+                    if (fused) {
+                        float *o = R.alloc(ACT((size_t)N * hs[i] * ws[i] * cpi));
+                        fp.base = running ? running : xs[i];
+                        fp.out = o;
+                        for (int q = 0; q < fp.nsrc; ++q) fp.src[q].x = xs[i + 1 + q];
+                        R.hr_fuse_up(fp, M.fuse[i][i + 1][0].label + "+up");
+                        if (running) R.release(running);
+                        running = o;
                     }
                     outs[i] = running;
                 }
@@ -2097,6 +2154,16 @@ int hmv_set_chain_fusion(hmv_handle h, int32_t enable) {
     HIPCHK(h, hipDeviceSynchronize());
     h->drop_graphs();
     h->chain_fuse = enable != 0;
+    h->reserved_batch = 0;
+    return HMV_OK;
+}
+
+int hmv_set_hr_fusion(hmv_handle h, int32_t enable) {
+    if (!h) return HMV_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    h->drop_graphs();
+    h->hr_fuse = enable != 0;
     h->reserved_batch = 0;
     return HMV_OK;
 }

@@ -352,6 +352,11 @@ class HandMvNet(torch.nn.Module):
         for h in self._engines.values():
             _lib.check(_lib.load().hmv_set_chain_fusion(h, int(enable)), h)
 
+    def set_hr_fusion(self, enable: bool = True):
+        """HRNet fuse layers: the up-sampling terms of a branch as one launch (default) / one conv launch per term (A/B, tests)."""
+        for h in self._engines.values():
+            _lib.check(_lib.load().hmv_set_hr_fusion(h, int(enable)), h)
+
     def poison_workspace(self, value: int = 0xFF):
         """Test hook: fills the workspace of the engine the last forward ran on with `value` bytes (0xFF = NaN patterns)."""
         hh, ww, idx, _, dt = self._last_key

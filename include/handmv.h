@@ -112,6 +112,14 @@ int hmv_set_tail_fusion(hmv_handle h, int32_t enable);
  * Both give the same bits; A/B runs and the identity test; the workspace is re-planned on the next forward. */
 int hmv_set_chain_fusion(hmv_handle h, int32_t enable);
 
+/* HRNet fuse layers (/root/reference/src/models/backbones/hrnet.py:194-212, y_i = relu(sum_j f_ij(x_j))): the up-sampling terms of an
+ * output branch (1x1 conv + BN + nearest up-sampling, j > i: always the last terms of the sum) as ONE launch where there are two or
+ * more of them (hr_fuse.hip: the branch's map is read once and written once), on (default) or off (one conv launch per term, each
+ * adding the running sum).  fp32 mode: equal up to the summation order inside a dot product; fp16 mode: the fused launch rounds the sum
+ * to fp16 once instead of after every term.  The split-precision mode always runs one launch per term.  A/B runs and the equivalence
+ * test; the workspace is re-planned on the next forward. */
+int hmv_set_hr_fusion(hmv_handle h, int32_t enable);
+
 /* Test hook: fills the reserved workspace with the byte `value` (0xFF: NaNs) on `stream`.  No stage may read workspace bytes that
  * an earlier stage of the SAME forward has not written, so a forward after poisoning returns the bits of one before it. */
 int hmv_poison_workspace(hmv_handle h, int32_t value, void *stream);

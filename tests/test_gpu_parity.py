@@ -174,13 +174,26 @@ def test_fusion_tail_on_engine_tokens(name, mode):
     ill-conditioned configurations, at 4 x the distance of the reference's own fp32 run from its float64 evaluation (hr40_lq:
     3.0e-4 / 7.1e-4 where worst-case amplification x token error would allow 1e-2 .. 1).  In every arithmetic mode the tail is
     fp32 (the fp16 path's q/k/v projections run as (hi, lo) pairs), so the fp16 path's learnable-query tail is pinned here even where
-    its end-to-end joints_cam floor is vacuous (fp16_noise.json: hr40_lq 1.1)."""
+    its end-to-end joints_cam floor is vacuous (fp16_noise.json: hr40_lq 1.1).  For the (hi, lo) modes of an ill-conditioned fixture the bar
+    follows the conditioning AT THE ENGINE'S OWN TOKENS (below)."""
     from oracle.oracle import Oracle
     m, cfg, sd, (x, bbox, intr), fx = _model(name)
     _set_mode(m, mode)
     got = _run(m, x, bbox, intr)
-    ref = Oracle(cfg, sd, "f64").fuse_tokens(got["tokens"])
+    o64 = Oracle(cfg, sd, "f64")
+    ref = o64.fuse_tokens(got["tokens"])
     tol_cam, tol_fused = cond_bounds(fx, TOL_TAIL_CAM, TOL_TAIL_FUSED)
+    if "amp_fused" in fx and mode != "f32":
+        # The fixture's conditioning figures were measured at the REFERENCE's tokens; the fp16 path's tokens are ~1e-3 away from them,
+        # and the un-normalised learnable-query blocks respond to their input very unevenly (logits of 1e4: measured in float64 at two
+        # token sets 2.4e-3 apart, a 1e-6 relative perturbation moves `fused` by 3.4e-5 at one and by 2.0e-2 at the other).  The (hi, lo)
+        # tail carries its operands to 2^-22, so its bar is taken at the operating point: twice what a 2^-19 relative perturbation of
+        # THESE tokens does to the float64 tail (tight where the point is benign -- 7e-5 --, honest where it is not).
+        rng = np.random.default_rng(1234)
+        tk = got["tokens"].astype(np.float64)
+        moved = o64.fuse_tokens((tk * (1.0 + 2.0 ** -19 * rng.standard_normal(tk.shape))).astype(np.float32))
+        tol_fused = max(tol_fused, 2.0 * rel_l2(moved["fused"], ref["fused"]))
+        tol_cam = max(tol_cam, 2.0 * rel_l2(moved["joints_cam"], ref["joints_cam"]))
     rep = {"fused": rel_l2(got["fused"], ref["fused"]), "joints_cam": rel_l2(got["joints_cam"], ref["joints_cam"]),
            "bounds": (tol_fused, tol_cam)}
     print(name, mode, rep)
@@ -862,6 +875,43 @@ def test_chained_launches_give_the_bits_of_one_launch_per_conv(case, frames_per_
             assert np.array_equal(chained[k], plain[k]), (nb, k, float(np.abs(chained[k] - plain[k]).max()))
             assert np.array_equal(chained[k], again[k]), (nb, k)
     m.set_chain_fusion(True)
+
+
+@pytest.mark.parametrize("case,size,nb", [("hr40_v4_128", 128, 2), ("hr40_v4_128", 256, 3), ("hr40_v4_128", 96, 2), ("hr64_tiny", 64, 2), ("hr64_tiny", 160, 1)])
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_hrnet_fuse_layers_in_one_launch(case, size, nb, mode):
+    """hr_fuse.hip: the up-sampling terms of an HRNet fuse layer (hrnet.py:194-212; 1x1 conv + BN + nearest up-sampling of every
+    coarser branch, the last terms of y_i = relu(sum_j f_ij(x_j))) as ONE launch per output branch that has two or more of them, against one
+    conv launch per term (each adding the running sum).  fp32: the same sums up to the order inside a dot product (exact-fp32 MFMAs
+    either way); fp16: the fused launch rounds the sum once, the per-term launches after every term.  Frame sizes that leave ragged
+    16 x 32 tiles (96: 24 x 24 maps; 160: 40 x 40) included; fewer launches; the poisoned-workspace rule holds.  The reference
+    fixtures themselves run with the fused launch (test_reference_fixture / test_fp16_path_within_the_noise_floor)."""
+    from handmvnet_amd import HandMvNet
+    from handmvnet_amd.synth import synth_inputs
+    cfg, (tp, mp, dp), sd, _, _ = load_case(case)
+    m = HandMvNet(tp, mp, dp)
+    m.load_state_dict(sd)
+    if mode == "f16":
+        m.half()
+    x, bbox, intr = synth_inputs(cfg, nb, 11 + nb, size)
+    m.set_hr_fusion(True)
+    fused = _run(m, x, bbox, intr)
+    n_fused = m.launch_count()
+    m.poison_workspace(0xFF)
+    again = _run(m, x, bbox, intr)
+    m.set_hr_fusion(False)
+    plain = _run(m, x, bbox, intr)
+    n_plain = m.launch_count()
+    m.set_hr_fusion(True)
+    # stage 3: branch 0 has two up-sampling terms (one launch instead of two) x 4 modules; stage 4: branches 0 and 1 (3 -> 1, 2 -> 1) x 3 modules
+    assert n_plain - n_fused == 4 * 1 + 3 * (2 + 1), (n_plain, n_fused)
+    tol = 2e-5 if mode == "f32" else 6e-3
+    for k in ("feat0", "heatmap"):
+        assert np.isfinite(fused[k]).all(), k
+        assert np.array_equal(fused[k], again[k]), k
+        assert rel_l2(fused[k], plain[k]) <= tol, (k, rel_l2(fused[k], plain[k]))
+    one = _run(m, x[:1], bbox[:1], intr[:1])
+    assert np.array_equal(one["joints_cam"][0], fused["joints_cam"][0])        # batch independence
 
 
 _CFG2_REF = {}

@@ -28,52 +28,79 @@ namespace hmv {
 
 typedef float hf32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 hf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 hf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int HRF_WAVES = 4, HRF_TW = 32, HRF_NVB = 8;   // waves; tile width; 16-wide k-steps per weight burst
 
-constexpr int HRF_UB = 10, HRF_UC = 10;   // units (4 channels of a pixel) a thread moves per batch in the load / apply phase
-template <typename T> struct hrf_vec_t;
-template <> struct hrf_vec_t<float> { typedef hf32x4 type; };
-template <> struct hrf_vec_t<_Float16> { typedef hf16x4 type; };
-template <typename T> using hrf_vec = typename hrf_vec_t<T>::type;
-template <typename T> __device__ __forceinline__ hrf_vec<T> hrf_zero();
-template <> __device__ __forceinline__ hf32x4 hrf_zero<float>() { return hf32x4{0.f, 0.f, 0.f, 0.f}; }
-template <> __device__ __forceinline__ hf16x4 hrf_zero<_Float16>() { return hf16x4{(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0}; }
-template <typename T> __device__ __forceinline__ hf32x4 hrf_cvt(hrf_vec<T> v);
-template <> __device__ __forceinline__ hf32x4 hrf_cvt<float>(hf32x4 v) { return v; }
-template <> __device__ __forceinline__ hf32x4 hrf_cvt<_Float16>(hf16x4 h) { return hf32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}; }
+constexpr int HRF_UB = 6, HRF_UC = 6;   // 16-byte units a thread moves per batch in the load / apply phase
+// 16-byte units: 4 fp32 or 8 fp16 channels of a pixel
+template <typename T> struct hrf_unit;
+template <> struct hrf_unit<float> {
+    static constexpr int E = 4;
+    hf32x4 v;
+    __device__ __forceinline__ void zero() { v = hf32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct hrf_unit<_Float16> {
+    static constexpr int E = 8;
+    hf16x8 v;
+    __device__ __forceinline__ void zero() { for (int i = 0; i < 8; ++i) v[i] = (_Float16)0; }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (_Float16)x; }
+};
 template <typename T> __device__ __forceinline__ hf32x4 hrf_load4(const T *p);
 template <> __device__ __forceinline__ hf32x4 hrf_load4<float>(const float *p) { return *reinterpret_cast<const hf32x4 *>(p); }
 template <> __device__ __forceinline__ hf32x4 hrf_load4<_Float16>(const _Float16 *p) {
     const hf16x4 h = *reinterpret_cast<const hf16x4 *>(p);
     return hf32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
-template <typename T> __device__ __forceinline__ void hrf_store4(T *p, hf32x4 v);
-template <> __device__ __forceinline__ void hrf_store4<float>(float *p, hf32x4 v) { *reinterpret_cast<hf32x4 *>(p) = v; }
-template <> __device__ __forceinline__ void hrf_store4<_Float16>(_Float16 *p, hf32x4 v) {
-    *reinterpret_cast<hf16x4 *>(p) = hf16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-}
 
-// One chunk of an item: acc[MBN blocks of 16 pixels][16 channels] += A[.][16 t0 .. 16 (t0 + nv)) . W^T over nv <= HRF_NVB sixteen-wide
-// k-steps whose weight vectors `b` are already in registers (requested one chunk ahead).
+// One item: G[P pixels][16 channels] = A[P][K] . W[16][K]^T + bias for MBN blocks of 16 pixels.  The weight vectors stream from L2 in
+// chunks of HRF_NVB sixteen-wide k-steps, chunk c + 1 requested before chunk c multiplies (clamped to the last step: every lane issues
+// the same loads), and stay in registers for all MBN blocks.
 template <typename T, int MBN>
-__device__ __forceinline__ void hrf_chunk(hf32x4 (&acc)[8], const T *arow, int lda, const hf32x4 (&b)[HRF_NVB], int t0, int nv) {
+__device__ __forceinline__ void hrf_item(const T *arow, int lda, const float *wrow, int nsteps, float *sgcol, int ldg, int P, float bv, int g) {
+    hf32x4 acc[MBN];
 #pragma unroll
-    for (int t = 0; t < HRF_NVB; ++t) {
-        if (t < nv) {   // (uniform)
-            hf32x4 a[MBN];
+    for (int mb = 0; mb < MBN; ++mb) acc[mb] = hf32x4{0.f, 0.f, 0.f, 0.f};
+    hf32x4 bcur[HRF_NVB], bnxt[HRF_NVB];
 #pragma unroll
-            for (int mb = 0; mb < MBN; ++mb) a[mb] = hrf_load4<T>(arow + mb * 16 * lda + 16 * (t0 + t));
+    for (int t = 0; t < HRF_NVB; ++t) bcur[t] = *reinterpret_cast<const hf32x4 *>(wrow + 16 * min(t, nsteps - 1));
+    for (int t0 = 0; t0 < nsteps; t0 += HRF_NVB) {
+        if (t0 + HRF_NVB < nsteps) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int mb = 0; mb < MBN; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][e], b[t][e], acc[mb], 0, 0, 0);
+            for (int t = 0; t < HRF_NVB; ++t) bnxt[t] = *reinterpret_cast<const hf32x4 *>(wrow + 16 * min(t0 + HRF_NVB + t, nsteps - 1));
         }
+#pragma unroll
+        for (int t = 0; t < HRF_NVB; ++t) {
+            if (t0 + t < nsteps) {   // (uniform)
+                hf32x4 a[MBN];
+#pragma unroll
+                for (int mb = 0; mb < MBN; ++mb) a[mb] = hrf_load4<T>(arow + mb * 16 * lda + 16 * (t0 + t));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mb = 0; mb < MBN; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][e], bcur[t][e], acc[mb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < HRF_NVB; ++t) bcur[t] = bnxt[t];
     }
+    // lane holds D[pixel 4 g + e][channel l15] of every pixel block; + bias -> G
+#pragma unroll
+    for (int mb = 0; mb < MBN; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int px = 16 * mb + 4 * g + e;
+            if (px < P) sgcol[px * ldg] = acc[mb][e] + bv;
+        }
 }
 
 template <typename T>
 __global__ __launch_bounds__(64 * HRF_WAVES) void hr_fuse_up_kernel(const HrFuseParams p) {
+    using U = hrf_unit<T>;
+    constexpr int E = U::E;
     extern __shared__ __attribute__((aligned(16))) char hsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -81,119 +108,93 @@ __global__ __launch_bounds__(64 * HRF_WAVES) void hr_fuse_up_kernel(const HrFuse
     const int n = blockIdx.x / (tyn * txn), trem = blockIdx.x - n * tyn * txn, ty = trem / txn, tx = trem - ty * txn;
     const int y0 = ty * p.th, x0 = tx * HRF_TW;
 
-    // ---- this wave's chunks (item = (source, 16-channel block); chunk = HRF_NVB k-steps of it): the weight vectors of chunk i + 1 are
-    // requested before chunk i multiplies, those of chunk 0 before anything else (they do not depend on the tile)
-    const int nch = p.nchunks[wave];
-    auto chunk_w = [&](int i, hf32x4 (&b)[HRF_NVB]) {
-        const int code = p.chunks[wave][i][0], t0 = p.chunks[wave][i][1], s = code >> 4, nb = code & 15;
-        const HrFuseSrc &S = p.src[s];
-        const float *wrow = S.w + (size_t)(16 * nb + l15) * S.ldw + 4 * g;
-        const int last = (S.C >> 4) - 1;
-#pragma unroll
-        for (int t = 0; t < HRF_NVB; ++t) b[t] = *reinterpret_cast<const hf32x4 *>(wrow + 16 * min(t0 + t, last));   // (clamped: every lane issues the same loads)
-    };
-    hf32x4 bcur[HRF_NVB], bnxt[HRF_NVB];
-    if (nch > 0) chunk_w(0, bcur);
-
-    // ---- phase A: the source tiles -> LDS ([P_s][C_s + 4] of T at a_off; rows past P_s are never written: their MFMA rows are never read).
-    // One unit = 4 channels of a pixel; a thread takes HRF_UB units of a source per batch and has all of a batch's loads in flight before
-    // the first LDS write waits for one.  Index arithmetic without divisions: the tile width is a power of two, the channel-group count
+    // ---- phase A: the source tiles -> LDS ([P_s][C_s + E] of T at a_off; rows past P_s are never written: their MFMA rows are never read).
+    // One unit = 16 bytes of a pixel; a thread takes HRF_UB units of a source per batch and has all of a batch's loads in flight before the
+    // first LDS write waits for one.  Index arithmetic without divisions: the tile width is a power of two, the unit count per pixel
     // divides by a host-computed reciprocal (units < 2^16)
     for (int s = 0; s < p.nsrc; ++s) {
         const HrFuseSrc &S = p.src[s];
         T *sa = reinterpret_cast<T *>(hsm + S.a_off);
-        const int lpw = 5 - S.shift, c4n = S.C >> 2, lda = S.C + 4, total = ((p.th >> S.shift) << lpw) * c4n;
+        const int lpw = 5 - S.shift, cun = S.C / E, lda = S.C + E, total = ((p.th >> S.shift) << lpw) * cun;
         const int sy0 = y0 >> S.shift, sx0 = x0 >> S.shift;
         const T *xs = reinterpret_cast<const T *>(S.x) + (size_t)n * S.H * S.W * S.ld;
         for (int u0 = 0; u0 < total; u0 += HRF_UB * 64 * HRF_WAVES) {
-            hrf_vec<T> v[HRF_UB];
+            U v[HRF_UB];
             int dsto[HRF_UB];
 #pragma unroll
             for (int k = 0; k < HRF_UB; ++k) {
                 const int u = u0 + k * 64 * HRF_WAVES + tid;
-                const int px = (int)__umulhi((unsigned)u, S.rcp4), c4 = u - px * c4n, r = px >> lpw, c = px & ((1 << lpw) - 1);
+                const int px = (int)__umulhi((unsigned)u, S.rcpu), cu = u - px * cun, r = px >> lpw, c = px & ((1 << lpw) - 1);
                 const int yy = sy0 + r, xx = sx0 + c;
-                dsto[k] = u < total ? px * lda + 4 * c4 : -1;
-                v[k] = hrf_zero<T>();
-                if (u < total && yy < S.H && xx < S.W) v[k] = *reinterpret_cast<const hrf_vec<T> *>(xs + (yy * S.W + xx) * S.ld + 4 * c4);
+                dsto[k] = u < total ? px * lda + E * cu : -1;
+                v[k].zero();
+                if (u < total && yy < S.H && xx < S.W) v[k] = *reinterpret_cast<const U *>(xs + (yy * S.W + xx) * S.ld + E * cu);
             }
 #pragma unroll
             for (int k = 0; k < HRF_UB; ++k)
-                if (dsto[k] >= 0) *reinterpret_cast<hrf_vec<T> *>(sa + dsto[k]) = v[k];
+                if (dsto[k] >= 0) *reinterpret_cast<U *>(sa + dsto[k]) = v[k];
         }
     }
     __syncthreads();
 
-    // ---- phase B
-    {
-        hf32x4 acc[8];
-        for (int i = 0; i < nch; ++i) {
-            if (i + 1 < nch) chunk_w(i + 1, bnxt);
-            const int code = p.chunks[wave][i][0], t0 = p.chunks[wave][i][1], s = code >> 4, nb = code & 15;
-            const HrFuseSrc &S = p.src[s];
-            const int P = (p.th >> S.shift) * (HRF_TW >> S.shift), mbn = (P + 15) >> 4, nsteps = S.C >> 4, nv = min(HRF_NVB, nsteps - t0);
-            const T *arow = reinterpret_cast<const T *>(hsm + S.a_off) + l15 * (S.C + 4) + 4 * g;
-            if (t0 == 0) {
-#pragma unroll
-                for (int mb = 0; mb < 8; ++mb) acc[mb] = hf32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            switch (mbn) {   // pixel blocks of the source tile: 8 / 2 / 1 (16-row tiles), 4 / 1 / 1 (8-row tiles)
-                case 8: hrf_chunk<T, 8>(acc, arow, S.C + 4, bcur, t0, nv); break;
-                case 4: hrf_chunk<T, 4>(acc, arow, S.C + 4, bcur, t0, nv); break;
-                case 2: hrf_chunk<T, 2>(acc, arow, S.C + 4, bcur, t0, nv); break;
-                default: hrf_chunk<T, 1>(acc, arow, S.C + 4, bcur, t0, nv); break;
-            }
-            if (t0 + nv == nsteps) {   // the item is complete: lane holds D[pixel 4 g + e][channel l15] of every pixel block; + bias -> G
-                float *sgcol = reinterpret_cast<float *>(hsm + S.g_off) + 16 * nb + l15;
-                const float bv = S.bias[16 * nb + l15];
-#pragma unroll
-                for (int mb = 0; mb < 8; ++mb)
-                    if (mb < mbn) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int px = 16 * mb + 4 * g + e;
-                            if (px < P) sgcol[px * p.ldg] = acc[mb][e] + bv;
-                        }
-                    }
-            }
-#pragma unroll
-            for (int t = 0; t < HRF_NVB; ++t) bcur[t] = bnxt[t];
+    // ---- phase B: this wave's items (source, 16-channel block)
+    for (int it = 0; it < p.nitems[wave]; ++it) {
+        const int code = p.items[wave][it], s = code >> 4, nb = code & 15;
+        const HrFuseSrc &S = p.src[s];
+        const int lda = S.C + E, P = (p.th >> S.shift) * (HRF_TW >> S.shift), mbn = (P + 15) >> 4;
+        const T *arow = reinterpret_cast<const T *>(hsm + S.a_off) + l15 * lda + 4 * g;
+        float *sgcol = reinterpret_cast<float *>(hsm + S.g_off) + 16 * nb + l15;
+        const float *wrow = S.w + (size_t)(16 * nb + l15) * S.ldw + 4 * g;
+        const float bv = S.bias[16 * nb + l15];
+        switch (mbn) {   // pixel blocks of the source tile: 8 / 2 / 1 (16-row tiles), 4 / 1 / 1 (8-row tiles)
+            case 8: hrf_item<T, 8>(arow, lda, wrow, S.C >> 4, sgcol, p.ldg, P, bv, g); break;
+            case 4: hrf_item<T, 4>(arow, lda, wrow, S.C >> 4, sgcol, p.ldg, P, bv, g); break;
+            case 2: hrf_item<T, 2>(arow, lda, wrow, S.C >> 4, sgcol, p.ldg, P, bv, g); break;
+            default: hrf_item<T, 1>(arow, lda, wrow, S.C >> 4, sgcol, p.ldg, P, bv, g); break;
         }
     }
     __syncthreads();
 
     // ---- phase C (batched like phase A)
     {
-        const int c4n = p.C >> 2, total = p.th * HRF_TW * c4n;
+        const int cun = p.C / E, total = p.th * HRF_TW * cun;
         const T *bs = reinterpret_cast<const T *>(p.base) + (size_t)n * p.H * p.W * p.ldc;
         T *os = reinterpret_cast<T *>(p.out) + (size_t)n * p.H * p.W * p.ldc;
         for (int u0 = 0; u0 < total; u0 += HRF_UC * 64 * HRF_WAVES) {
-            hrf_vec<T> bv[HRF_UC];
-            int go[HRF_UC], gof[HRF_UC];   // global element offset (-1: no pixel); (tile pixel << 8) | channel group
+            U bv[HRF_UC];
+            int go[HRF_UC], gof[HRF_UC];   // global element offset (-1: no pixel); (tile pixel << 8) | unit of the pixel
 #pragma unroll
             for (int k = 0; k < HRF_UC; ++k) {
                 const int u = u0 + k * 64 * HRF_WAVES + tid;
-                const int px = (int)__umulhi((unsigned)u, p.rcp4), c4 = u - px * c4n, r = px >> 5, c = px & 31;
+                const int px = (int)__umulhi((unsigned)u, p.rcpu), cu = u - px * cun, r = px >> 5, c = px & 31;
                 const int yy = y0 + r, xx = x0 + c;
                 const bool ok = u < total && yy < p.H && xx < p.W;
-                go[k] = ok ? (yy * p.W + xx) * p.ldc + 4 * c4 : -1;
-                gof[k] = (px << 8) | c4;
-                bv[k] = hrf_zero<T>();
-                if (ok) bv[k] = *reinterpret_cast<const hrf_vec<T> *>(bs + go[k]);
+                go[k] = ok ? (yy * p.W + xx) * p.ldc + E * cu : -1;
+                gof[k] = (px << 8) | cu;
+                bv[k].zero();
+                if (ok) bv[k] = *reinterpret_cast<const U *>(bs + go[k]);
             }
 #pragma unroll
             for (int k = 0; k < HRF_UC; ++k) {
                 if (go[k] < 0) continue;
-                hf32x4 v = hrf_cvt<T>(bv[k]);
-                const int px = gof[k] >> 8, c4 = gof[k] & 255, r = px >> 5, c = px & 31;
+                const int px = gof[k] >> 8, cu = gof[k] & 255, r = px >> 5, c = px & 31;
+                float v[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = bv[k].get(e);
                 for (int s = 0; s < p.nsrc; ++s) {
                     const HrFuseSrc &S = p.src[s];
-                    const float *sg = reinterpret_cast<const float *>(hsm + S.g_off);
-                    const int spx = (r >> S.shift) * (HRF_TW >> S.shift) + (c >> S.shift);
-                    v += *reinterpret_cast<const hf32x4 *>(sg + spx * p.ldg + 4 * c4);
+                    const float *sg = reinterpret_cast<const float *>(hsm + S.g_off) + ((r >> S.shift) * (HRF_TW >> S.shift) + (c >> S.shift)) * p.ldg + E * cu;
+#pragma unroll
+                    for (int q = 0; q < E / 4; ++q) {
+                        const hf32x4 gq = *reinterpret_cast<const hf32x4 *>(sg + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q + e] += gq[e];
+                    }
                 }
-                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                hrf_store4<T>(os + go[k], v);
+                U o;
+#pragma unroll
+                for (int e = 0; e < E; ++e) o.set(e, p.relu ? fmaxf(v[e], 0.f) : v[e]);
+                *reinterpret_cast<U *>(os + go[k]) = o;
             }
         }
     }
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(64 * HRF_WAVES) void hr_fuse_up_kernel(const HrFuse
 // ====================================================================== host side
 // Fills the tile height, the LDS layout and the item lists; false: the shape has no fused form (the caller runs the per-term launches)
 bool hr_fuse_up_plan(HrFuseParams &p) {
-    if (p.nsrc < 1 || p.nsrc > 3 || p.C % 4 || p.C > 256 || p.ldc % 4 || p.N <= 0 || p.H <= 0 || p.W <= 0) return false;
+    if (p.nsrc < 1 || p.nsrc > 3 || p.C % (p.f16 ? 8 : 4) || p.C > 256 || p.ldc % 4 || p.N <= 0 || p.H <= 0 || p.W <= 0) return false;
     if ((long long)p.H * p.W * p.ldc >= (1ll << 31) || p.C < 8) return false;   // 32-bit element offsets inside an image
     const int esz = p.f16 ? 2 : 4;
     for (int s = 0; s < p.nsrc; ++s) {
@@ -210,8 +211,9 @@ bool hr_fuse_up_plan(HrFuseParams &p) {
         if (S.shift < 1 || S.shift > 3 || S.C % 16 || S.C > 512 || S.ld % 4 || S.ldw % 4 || S.ldw < S.C) return false;
         if (S.H != (p.H >> S.shift) || S.W != (p.W >> S.shift) || (S.H << S.shift) != p.H || (S.W << S.shift) != p.W) return false;
     }
-    p.rcp4 = (unsigned)(((1ull << 32) + (unsigned)(p.C / 4) - 1) / (unsigned)(p.C / 4));   // ceil(2^32 / (C / 4)): exact quotients for units < 2^16
-    for (int s = 0; s < p.nsrc; ++s) p.src[s].rcp4 = (unsigned)(((1ull << 32) + (unsigned)(p.src[s].C / 4) - 1) / (unsigned)(p.src[s].C / 4));
+    const int epu = p.f16 ? 8 : 4;   // elements per 16-byte unit
+    p.rcpu = (unsigned)(((1ull << 32) + (unsigned)(p.C / epu) - 1) / (unsigned)(p.C / epu));   // ceil(2^32 / units per pixel): exact quotients for units < 2^16
+    for (int s = 0; s < p.nsrc; ++s) p.src[s].rcpu = (unsigned)(((1ull << 32) + (unsigned)(p.src[s].C / epu) - 1) / (unsigned)(p.src[s].C / epu));
     const int nbn = (p.C + 15) / 16;   // 16-channel blocks (the weight / bias rows past C are zeros: Layer's Cout_pad)
     p.ldg = 16 * nbn + 4;
     for (int th : {16, 8}) {
@@ -227,15 +229,15 @@ bool hr_fuse_up_plan(HrFuseParams &p) {
             const int P = (th >> S.shift) * (HRF_TW >> S.shift);
             if ((th >> S.shift) < 1) { ok = false; break; }
             S.a_off = (int)off;
-            off += ((size_t)P * (S.C + 4) * esz + 15) / 16 * 16;
+            off += ((size_t)P * (S.C + epu) * esz + 15) / 16 * 16;
         }
         if (!ok) continue;
         // a pixel block of 16 MFMA rows may start up to 15 rows before a tile's end: keep that much readable behind the last A tile
         const HrFuseSrc &L = p.src[order[p.nsrc - 1]];
-        size_t need = (size_t)L.a_off + (size_t)(((th >> L.shift) * (HRF_TW >> L.shift) + 15) / 16 * 16) * (L.C + 4) * esz;
+        size_t need = (size_t)L.a_off + (size_t)(((th >> L.shift) * (HRF_TW >> L.shift) + 15) / 16 * 16) * (L.C + epu) * esz;
         for (int a = 0; a < p.nsrc; ++a) {   // (every A tile's padded extent)
             const HrFuseSrc &S = p.src[order[a]];
-            const size_t ext = (size_t)S.a_off + (size_t)(((th >> S.shift) * (HRF_TW >> S.shift) + 15) / 16 * 16) * (S.C + 4) * esz;
+            const size_t ext = (size_t)S.a_off + (size_t)(((th >> S.shift) * (HRF_TW >> S.shift) + 15) / 16 * 16) * (S.C + epu) * esz;
             if (ext > need) need = ext;
         }
         if (off < need) off = (need + 15) / 16 * 16;
@@ -263,18 +265,13 @@ bool hr_fuse_up_plan(HrFuseParams &p) {
         for (int b = a + 1; b < ni; ++b)
             if (items[b].cost > items[a].cost) { const It t = items[a]; items[a] = items[b]; items[b] = t; }
     int load[HRF_WAVES] = {0, 0, 0, 0};
-    for (int w = 0; w < HRF_WAVES; ++w) p.nchunks[w] = 0;
+    for (int w = 0; w < HRF_WAVES; ++w) p.nitems[w] = 0;
     for (int a = 0; a < ni; ++a) {
         int w = 0;
         for (int q = 1; q < HRF_WAVES; ++q)
             if (load[q] < load[w]) w = q;
-        const int nsteps = p.src[items[a].code >> 4].C / 16;
-        for (int t0 = 0; t0 < nsteps; t0 += HRF_NVB) {   // the item's chunks, in order
-            if (p.nchunks[w] >= 24) return false;
-            p.chunks[w][p.nchunks[w]][0] = (unsigned char)items[a].code;
-            p.chunks[w][p.nchunks[w]][1] = (unsigned char)t0;
-            ++p.nchunks[w];
-        }
+        if (p.nitems[w] >= 12) return false;
+        p.items[w][p.nitems[w]++] = (unsigned char)items[a].code;
         load[w] += items[a].cost;
     }
     return true;

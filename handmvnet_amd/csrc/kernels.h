@@ -236,13 +236,13 @@ hipError_t launch_ff_block(const FfBlockParams &p, hipStream_t s);
 // hr_fuse.hip: the up-sampling terms of an HRNet fuse layer (hrnet.py:194-212) as one launch:
 //   out = act(((base + G_0) + G_1) + G_2),  G_s = W_s x_s + b_s at x_s's resolution, read at (y >> shift_s, x >> shift_s)
 // base / out / x_s: NHWC rows of fp32 or fp16 (f16); w_s fp32 [>= C rows][ldw], bias_s fp32; sources in the reference's order (ascending j)
-struct HrFuseSrc { const void *x; const float *w; const float *bias; int C, ld, ldw, shift, H, W, a_off, g_off; unsigned rcp4; };
+struct HrFuseSrc { const void *x; const float *w; const float *bias; int C, ld, ldw, shift, H, W, a_off, g_off; unsigned rcpu; };
 struct HrFuseParams {
     const void *base; void *out;
     int N, H, W, C, ldc, nsrc, relu, f16;
     HrFuseSrc src[3];
-    int th, lds, ldg; unsigned rcp4;        // filled by hr_fuse_up_plan: tile height, LDS bytes, G row stride, ceil(2^32 / (C / 4))
-    int nchunks[4]; unsigned char chunks[4][24][2];   // per wave: (source << 4 | 16-channel block, first k-step) of its weight chunks, in order
+    int th, lds, ldg; unsigned rcpu;        // filled by hr_fuse_up_plan: tile height, LDS bytes, G row stride, ceil(2^32 / 16-byte units per pixel)
+    int nitems[4]; unsigned char items[4][12];   // per wave: its items (source << 4 | 16-channel block), longest first
 };
 bool hr_fuse_up_plan(HrFuseParams &p);      // false: no fused form for this shape (run the per-term launches)
 hipError_t launch_hr_fuse_up(const HrFuseParams &p, hipStream_t s);

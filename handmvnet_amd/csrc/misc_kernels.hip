@@ -687,9 +687,8 @@ hipError_t launch_splitk_layernorm(const float *slab, int S, int rows, int lds, 
 //                           the accumulator layout S^T came out in, so P never leaves the registers
 // The k order inside every 8-wide group is permuted identically for both operands (16-byte reads).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int ATT_WAVES = 4;
-// D = head width: 128 (MultiHeadAttention, layers.py:177-237) or 256 (MultiHeadAttentionLearnableQuery, layers.py:240-301)
-template <int D> struct AttShape {
+// ATT_WAVES: waves per workgroup; the 32-key chunks of the key range are dealt round-robin to them (4 everywhere: launch_attention_any)
+template <int D, int ATT_WAVES> struct AttShape {
     static constexpr int LDK = D + 4;                           // Q block row stride (floats): conflict-free ds_read_b128 of the B operand
     static constexpr int NC = D / 32;                           // 32-channel blocks of the head
     static constexpr int Q_FLOATS = 32 * LDK;
@@ -704,10 +703,10 @@ template <int D> struct AttShape {
 #endif
 // q rows: q + (b * q_bstride + i) * q_ld + h * D;  k / v rows: k + (b * T + j) * kv_ld + h * D for keys j < Tk (the caller offsets
 // k / v to the first key);  out rows [B * Tq][8 * D]
-template <int D>
+template <int D, int ATT_WAVES>
 __global__ __launch_bounds__(64 * ATT_WAVES, D == 128 ? HMV_ATT_OCC : 1) void attention_mfma_kernel(const float *__restrict__ q, int q_ld, int q_bstride,
         const float *__restrict__ k, const float *__restrict__ v, int kv_ld, int T, int Tq, int Tk, int nqb, float *__restrict__ out, int pairs) {
-    using SH = AttShape<D>;
+    using SH = AttShape<D, ATT_WAVES>;
     constexpr int NC = SH::NC, NU = D / 8, NV = D / 32;   // K vectors per lane, V vectors per lane and quarter chunk
     extern __shared__ __attribute__((aligned(16))) float att_smem[];
     const int qblk = blockIdx.x % nqb, bh = blockIdx.x / nqb;
@@ -723,6 +722,7 @@ __global__ __launch_bounds__(64 * ATT_WAVES, D == 128 ? HMV_ATT_OCC : 1) void at
     float *sVw = att_smem + SH::Q_FLOATS + wave * SH::V_FLOATS;             // [8][D], this wave's
 
     // every global load of a wave's first chunk is issued before anything waits
+    constexpr bool PREFETCH = D == 128;
     f32x4 kf[NU], va[NV], vb_[NV];
     int kc = wave;
 #define ATT_LOAD_K(KC)                                                                                  \
@@ -766,10 +766,10 @@ __global__ __launch_bounds__(64 * ATT_WAVES, D == 128 ? HMV_ATT_OCC : 1) void at
         ATT_LOAD_K(kc);
         ATT_LOAD_V(kc * 32, va);
     }
-    // Q block (rows >= Tq are zeros), shared by the 4 waves
+    // Q block (rows >= Tq are zeros), shared by the waves
 #pragma unroll
-    for (int it = 0; it < D / 32; ++it) {
-        const int idx = it * 256 + tid, r = idx / (D / 4), c4 = idx % (D / 4), row = qblk * 32 + r;
+    for (int it = 0; it < (8 * D) / (64 * ATT_WAVES); ++it) {
+        const int idx = it * (64 * ATT_WAVES) + tid, r = idx / (D / 4), c4 = idx % (D / 4), row = qblk * 32 + r;
         f32x4 qv = {0.f, 0.f, 0.f, 0.f};
         if (row < Tq) qv = *reinterpret_cast<const f32x4 *>(qb + (size_t)row * q_ld + 4 * c4);
         *reinterpret_cast<f32x4 *>(&sQ[r * SH::LDK + 4 * c4]) = qv;
@@ -792,6 +792,8 @@ __global__ __launch_bounds__(64 * ATT_WAVES, D == 128 ? HMV_ATT_OCC : 1) void at
             _Pragma("unroll") for (int e = 0; e < 4; ++e)                                               \
                 sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[e], sacc, 0, 0, 0);            \
         }                                                                                               \
+        /* the key rows of this wave's NEXT chunk fly during the softmax and the P V products of this one (their registers are free) */ \
+        if (PREFETCH && (KC) + ATT_WAVES < nkc) ATT_LOAD_K((KC) + ATT_WAVES);                           \
         ATT_LOAD_V((KC) * 32 + 8, vb_);   /* the next 8 keys fly during the softmax */                  \
         /* register e = key (e&3) + 8(e>>2) + 4 half of the chunk, for query l31 */                     \
         float mx = -INFINITY;                                                                           \
@@ -820,17 +822,23 @@ __global__ __launch_bounds__(64 * ATT_WAVES, D == 128 ? HMV_ATT_OCC : 1) void at
         ATT_LOAD_V((KC) * 32 + 24, vb_);                                                                \
         ATT_PV(1);                                                                                      \
         ATT_STORE_V(va);                                                                                \
+        if (PREFETCH && (KC) + ATT_WAVES < nkc) ATT_LOAD_V(((KC) + ATT_WAVES) * 32, va);   /* ... and its first 8 value rows */ \
         ATT_PV(2);                                                                                      \
         ATT_STORE_V(vb_);                                                                               \
         ATT_PV(3);                                                                                      \
         __builtin_amdgcn_wave_barrier();                                                                \
     } while (0)
     if (kc < nkc) {
-        ATT_CHUNK(kc);
-        for (kc += ATT_WAVES; kc < nkc; kc += ATT_WAVES) {
-            ATT_LOAD_K(kc);
-            ATT_LOAD_V(kc * 32, va);
+        // 128-wide heads: a chunk requests the operands of this wave's next one (round 4); the 256-wide ones have no registers for that
+        if constexpr (PREFETCH) {
+            for (; kc < nkc; kc += ATT_WAVES) ATT_CHUNK(kc);
+        } else {
             ATT_CHUNK(kc);
+            for (kc += ATT_WAVES; kc < nkc; kc += ATT_WAVES) {
+                ATT_LOAD_K(kc);
+                ATT_LOAD_V(kc * 32, va);
+                ATT_CHUNK(kc);
+            }
         }
     }
 #undef ATT_CHUNK
@@ -893,23 +901,31 @@ __global__ __launch_bounds__(64 * ATT_WAVES, D == 128 ? HMV_ATT_OCC : 1) void at
         }
     }
 }
+template <int D, int W>
+static hipError_t launch_attention_w(const float *q, int q_ld, int q_bstride, const float *k, const float *v, int kv_ld, int B, int T, int Tq,
+                                     int Tk, float *out, hipStream_t s, int pairs, int nqb) {
+    static bool configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    const int lds = AttShape<D, W>::LDS_FLOATS * (int)sizeof(float);
+    if (!configured[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel<D, W>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        configured[dev] = true;
+    }
+    hipLaunchKernelGGL((attention_mfma_kernel<D, W>), dim3((unsigned)B * 8 * nqb), dim3(64 * W), lds, s, q, q_ld, q_bstride, k, v, kv_ld, T, Tq,
+                       Tk, nqb, out, pairs);
+    return hipGetLastError();
+}
 template <int D>
 static hipError_t launch_attention_any(const float *q, int q_ld, int q_bstride, const float *k, const float *v, int kv_ld, int B, int T, int Tq,
                                        int Tk, float *out, hipStream_t s, int pairs = 0) {
     if (Tk <= 0 || Tq <= 0 || B <= 0) return hipErrorInvalidValue;
-    static bool configured[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    const int lds = AttShape<D>::LDS_FLOATS * (int)sizeof(float);
-    if (!configured[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_mfma_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        configured[dev] = true;
-    }
     const int nqb = (Tq + 31) >> 5;
-    hipLaunchKernelGGL(attention_mfma_kernel<D>, dim3((unsigned)B * 8 * nqb), dim3(64 * ATT_WAVES), lds, s, q, q_ld, q_bstride, k, v, kv_ld, T, Tq,
-                       Tk, nqb, out, pairs);
-    return hipGetLastError();
+    // (measured in round 4, tools/att_probe.py: TWO waves per workgroup -- six chunks as 3 : 3 instead of 2 : 2 : 1 : 1, four workgroups per CU --
+    // take 86.4 us where four take 88.7 at B = 32 x 168 tokens and 22.7 against 18.4 us at B = 1: the launch is bound by its fp32 MFMA time
+    // plus the latencies two waves per SIMD cannot hide, not by the split)
+    return launch_attention_w<D, 4>(q, q_ld, q_bstride, k, v, kv_ld, B, T, Tq, Tk, out, s, pairs, nqb);
 }
 hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s, int pairs) {
     return launch_attention_any<128>(qkv, 3 * 1024, T, qkv + (size_t)koff * 3072 + 1024, qkv + (size_t)koff * 3072 + 2048, 3 * 1024, B, T, Tq, Tk, out, s, pairs);

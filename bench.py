@@ -216,8 +216,8 @@ def measure(args, world, rank, dev):
 
     for _ in range(args.warmup):
         step()
-    if args.no_hr_fusion:              # A/B: one conv launch per HRNet fuse term (the engine exists after the first step)
-        model.set_hr_fusion(False)
+    if args.no_hr_fusion or args.hr_mode >= 0:   # A/B: HRNet fuse-layer fusion (bit 0) / branch overlap (bit 1) off (the engine exists after the first step)
+        model.set_hr_fusion(0 if args.no_hr_fusion else args.hr_mode)
         step()
     if args.graphs:
         model.use_graphs(True)
@@ -375,7 +375,8 @@ def main():
                          "separate instrumented pass afterwards")
     ap.add_argument("--graphs", action="store_true", help="opt into hipGraph replay for the un-instrumented steps")
     ap.add_argument("--per-layer", default="", help="write per-layer launch timings (JSON) to this file")
-    ap.add_argument("--no-hr-fusion", action="store_true", help="A/B: HRNet fuse layers as one conv launch per term (hr_fuse.hip off)")
+    ap.add_argument("--no-hr-fusion", action="store_true", help="A/B: HRNet fuse layers as one conv launch per term, one stream")
+    ap.add_argument("--hr-mode", type=int, default=-1, help="A/B: hmv_set_hr_fusion mode (bit 0: fused fuse layers, bit 1: branch overlap)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the fp16 (BASELINE configs[4]) leg that the default full run appends as `configs4_fp16`")
     ap.add_argument("--launch-check", action="store_true",

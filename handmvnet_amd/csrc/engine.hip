@@ -212,6 +212,10 @@ struct hmv_engine {
     // select the launch-per-op path (A/B runs, the equivalence test).  Part of the workspace plan: changing them re-plans.
     bool ff_fuse = true, cheb_fuse = true;
     bool hr_fuse = true;      // HRNet: the up-sampling terms of a fuse layer as one launch (hr_fuse.hip); hmv_set_hr_fusion(h, 0): one launch per term
+    bool hr_overlap = true;   // HRNet, fp16-kernel modes: a module's lowest-resolution branch runs on a second stream beside the branch above it
+                              // (hmv_set_hr_fusion bit 1; measured hr40 fp16 -1.2 %, f32x3 -0.9 %, fp32 +0.3 %: off in the fp32 mode)
+    hipStream_t aux = nullptr;            // the second stream (forked from / joined into the caller's stream by events: also under graph capture)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool chain_fuse = true;   // conv3 -> next block's conv1 in one launch (conv_stream.hip chain); hmv_set_chain_fusion(h, 0) / HMV_NO_CHAIN=1
     std::vector<GraphEntry> gcache;
     std::vector<GraphKey> gseen;     // buffer sets run eagerly once and not captured yet (callers often alternate between a few)
@@ -1094,7 +1098,30 @@ struct Runner {
         if (!dry && h->arena_bytes && A.high > h->arena_bytes && rc == HMV_OK) rc = h->fail(HMV_ERR_STATE, "workspace plan exceeded its reservation");
         return ptr;
     }
-    void release(float *p) { A.release(p); }
+    // Two streams (HRNet: a module's last branch beside the one above it): nothing freed inside the region may be handed out again before
+    // the streams have joined -- its last user may still be running on the other stream -- so releases wait in `deferred` until join().
+    // Same alloc / release sequence in the planning run.
+    bool defer = false;
+    std::vector<float *> deferred;
+    void release(float *p) {
+        if (defer && p) deferred.push_back(p);
+        else A.release(p);
+    }
+    void fork() {   // the second stream starts behind everything enqueued so far
+        defer = true;
+        if (dry || rc != HMV_OK) return;
+        check(hipEventRecord(h->ev_fork, s), "hipEventRecord");
+        check(hipStreamWaitEvent(h->aux, h->ev_fork, 0), "hipStreamWaitEvent");
+    }
+    void join() {   // ... and the first one continues behind everything the second has enqueued
+        if (!dry && rc == HMV_OK) {
+            check(hipEventRecord(h->ev_join, h->aux), "hipEventRecord");
+            check(hipStreamWaitEvent(s, h->ev_join, 0), "hipStreamWaitEvent");
+        }
+        defer = false;
+        for (float *p : deferred) A.release(p);
+        deferred.clear();
+    }
 
     void check(hipError_t e, const char *what) {
         if (e != hipSuccess && rc == HMV_OK) rc = h->fail(HMV_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
@@ -1356,6 +1383,11 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                 float *heatmap, hipStream_t s, bool dry, Arena &A) {
     Runner R{h, s, dry, HMV_OK, A};
     const hmv_config &c = h->cfg;
+    if (!dry && h->hrnet && h->hr_overlap && c.dtype != HMV_F32 && !h->aux) {   // (the first forward of a handle is never a captured one)
+        if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+            return h->fail(HMV_ERR_HIP, "second stream for the HRNet branches");
+    }
     const int V = c.num_views, N = B * V, H = c.height, W = c.width;
     const int d = h->d, ldt = h->ldt;
     // fp16 path: the conv stack (stem .. pose_net / sample convs) stores activations as fp16; heat-map logits,
@@ -1457,8 +1489,15 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
             for (int i = 0; i < npre; ++i)
                 if (!moved[i]) R.release(pre[i]);
             for (const HrModule &M : hr.stage[st]) {   // HighResolutionModule.forward (hrnet.py:194-212)
+                // Four branches: the lowest-resolution one (320 / 512 channels on 1/32-size maps: a few hundred small tiles per conv, bound
+                // by request latency) runs on the second stream BESIDE the branch above it (one round of 256 x 192 tiles, latency-bound too):
+                // their workgroups share the CUs.  The two highest-resolution branches own the chip with persistent kernels and stay alone.
+                const bool overlap = h->hr_overlap && h16 && nbr == 4 && (dry || h->aux != nullptr);
                 for (int b = 0; b < nbr; ++b) {
                     const int cp = cpad(hr.ch[b]);
+                    if (overlap && b == 2) R.fork();
+                    const hipStream_t main_s = R.s;
+                    if (overlap && b == 3) R.s = h->aux;
                     for (int blk = 0; blk < 4; ++blk) {
                         float *t = R.alloc(ACT((size_t)N * hs[b] * ws[b] * cp));
                         R.conv(M.br[b][blk][0], xs[b], N, hs[b], ws[b], 1, 1, 1, t, cp, nullptr, 0, ACT_RELU, hs[b], ws[b], 0, 0, 0, 0, 0,
@@ -1470,6 +1509,8 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
                         R.release(xs[b]);
                         xs[b] = y;
                     }
+                    R.s = main_s;
+                    if (overlap && b == 3) R.join();
                 }
                 // fuse: y_i = relu(sum_j f_ij(x_j)).  Every non-identity term is a conv at branch i's resolution whose
                 // epilogue adds the running sum (the identity term x_i rides along as the first residual); the
@@ -2110,6 +2151,9 @@ void hmv_destroy(hmv_handle h) {
     (void)hipDeviceSynchronize();
     h->drop_graphs();
     if (h->gstream) (void)hipStreamDestroy(h->gstream);
+    if (h->aux) (void)hipStreamDestroy(h->aux);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (void *p : h->dev_allocs) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);
     for (float *p : {h->cap_feat0, h->cap_coords, h->cap_tokens, h->cap_fused})
@@ -2163,7 +2207,8 @@ int hmv_set_hr_fusion(hmv_handle h, int32_t enable) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipDeviceSynchronize());
     h->drop_graphs();
-    h->hr_fuse = enable != 0;
+    h->hr_fuse = (enable & 1) != 0;
+    h->hr_overlap = (enable & 2) != 0;
     h->reserved_batch = 0;
     return HMV_OK;
 }

@@ -352,10 +352,12 @@ class HandMvNet(torch.nn.Module):
         for h in self._engines.values():
             _lib.check(_lib.load().hmv_set_chain_fusion(h, int(enable)), h)
 
-    def set_hr_fusion(self, enable: bool = True):
-        """HRNet fuse layers: the up-sampling terms of a branch as one launch (default) / one conv launch per term (A/B, tests)."""
+    def set_hr_fusion(self, enable=True):
+        """HRNet: bit 0 -- the up-sampling terms of a fuse layer as one launch / one conv launch per term; bit 1 -- a four-branch module's
+        last branch on a second stream beside the branch above it / one stream.  True = 3 (default: both), False = 0 (A/B, tests)."""
+        mode = 3 if enable is True else (0 if enable is False else int(enable))
         for h in self._engines.values():
-            _lib.check(_lib.load().hmv_set_hr_fusion(h, int(enable)), h)
+            _lib.check(_lib.load().hmv_set_hr_fusion(h, mode), h)
 
     def poison_workspace(self, value: int = 0xFF):
         """Test hook: fills the workspace of the engine the last forward ran on with `value` bytes (0xFF = NaN patterns)."""

@@ -116,8 +116,11 @@ int hmv_set_chain_fusion(hmv_handle h, int32_t enable);
  * output branch (1x1 conv + BN + nearest up-sampling, j > i: always the last terms of the sum) as ONE launch where there are two or
  * more of them (hr_fuse.hip: the branch's map is read once and written once), on (default) or off (one conv launch per term, each
  * adding the running sum).  fp32 mode: equal up to the summation order inside a dot product; fp16 mode: the fused launch rounds the sum
- * to fp16 once instead of after every term.  The split-precision mode always runs one launch per term.  A/B runs and the equivalence
- * test; the workspace is re-planned on the next forward. */
+ * to fp16 once instead of after every term.  The split-precision mode always runs one launch per term.
+ * Bit 1 of `enable` (round 4; fp16-kernel modes only -- measured hr40 fp16 -1.2 %, f32x3 -0.9 %, fp32 +0.3 %): a four-branch module's lowest-resolution branch (its eight 3x3 convs) is enqueued on a second stream of the
+ * handle beside the branch above it -- both are a few hundred latency-bound tiles per conv and share the CUs; forked from and joined
+ * into the caller's stream by events (also under hipGraph capture), same kernels and bits.  enable: 0 neither, 1 fused fuse layers
+ * only, 2 branch overlap only, 3 both (default).  A/B runs and the equivalence test; the workspace is re-planned on the next forward. */
 int hmv_set_hr_fusion(hmv_handle h, int32_t enable);
 
 /* Test hook: fills the reserved workspace with the byte `value` (0xFF: NaNs) on `stream`.  No stage may read workspace bytes that

@@ -30,7 +30,7 @@ def _call_into(m, x, bbox, cam, outs):
     rc = _lib.load().hmv_forward(h, b, x.data_ptr(), bb.data_ptr(), it.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
                                  outs[2].data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, h)
-    m._last_key = (x.shape[-2], x.shape[-1], 0, b, 0)
+    m._last_key = (x.shape[-2], x.shape[-1], 0, b, m._dtype)
 
 
 def _outs(x, m=None):
@@ -72,6 +72,32 @@ def test_graph_replay_is_bit_identical_to_eager(name):
     torch.cuda.synchronize()
     for a, b in zip(outs, eager):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["hr40_tiny", "hr40_v4_128"])
+def test_graph_capture_takes_the_second_stream_along(name):
+    """fp16-kernel modes run a four-branch HRNet module's last branch on a second stream of the handle (forked from / joined into the
+    caller's stream by events): under capture that stream joins the capture, and the replay gives the eager bits."""
+    m, x, bbox, cam = _model(name)
+    m.half()
+    bb = bbox.reshape(-1, 4).contiguous().float()
+    cam = {"intrinsic": cam["intrinsic"].reshape(-1, 4).contiguous().float()}
+    m.use_graphs(False)
+    eager = _outs(x, m)
+    _call_into(m, x, bb, cam, eager)
+    torch.cuda.synchronize()
+    m.use_graphs(True)
+    outs = _outs(x, m)
+    for i in range(4):                      # eager, capture + first launch, replay, replay
+        for o in outs:
+            o.fill_(float("nan"))
+        _call_into(m, x, bb, cam, outs)
+        torch.cuda.synchronize()
+        for a, b in zip(outs, eager):
+            assert torch.equal(a, b), (name, i)
+    cached, replays = m.graph_stats()
+    assert cached == 1 and replays == 2
+    m.use_graphs(False)
 
 
 def test_graph_cache_is_keyed_by_buffers_and_bounded():

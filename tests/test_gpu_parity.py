@@ -914,6 +914,32 @@ def test_hrnet_fuse_layers_in_one_launch(case, size, nb, mode):
     assert np.array_equal(one["joints_cam"][0], fused["joints_cam"][0])        # batch independence
 
 
+@pytest.mark.parametrize("mode", ["f16", "f32x3"])
+def test_hrnet_last_branch_on_a_second_stream(mode):
+    """fp16-kernel modes, four-branch HRNet modules: the lowest-resolution branch's eight convs are enqueued on a second stream of the handle
+    beside the branch above it (fork / join by events; nothing freed inside the region is handed out again before the join).  Same
+    kernels, same bits as one stream (hmv_set_hr_fusion mode 1); the poisoned-workspace rule holds (hipGraph capture with the second stream:
+    tests/test_gpu_graphs.py)."""
+    from handmvnet_amd import HandMvNet
+    from handmvnet_amd.synth import synth_inputs
+    cfg, (tp, mp, dp), sd, _, _ = load_case("hr40_v4_128")
+    m = HandMvNet(tp, mp, dp)
+    m.load_state_dict(sd)
+    _set_mode(m, mode)
+    x, bbox, intr = synth_inputs(cfg, 3, 21, 256)
+    m.set_hr_fusion(3)
+    two = _run(m, x, bbox, intr)
+    m.poison_workspace(0xFF)
+    again = _run(m, x, bbox, intr)
+    m.set_hr_fusion(1)
+    one = _run(m, x, bbox, intr)
+    m.set_hr_fusion(3)
+    for k in ("feat0", "heatmap", "tokens", "joints_cam", "joints_crop_img"):
+        assert np.isfinite(two[k]).all(), k
+        assert np.array_equal(two[k], one[k]), (k, float(np.abs(two[k] - one[k]).max()))
+        assert np.array_equal(two[k], again[k]), k
+
+
 _CFG2_REF = {}
 
 

@@ -2404,6 +2404,64 @@ extern "C" int hmv_op_conv2d_ex(int32_t device, int32_t dtype, const float *in, 
                          out, false, nullptr, stream);
 }
 
+// The up-sampling terms of an HRNet fuse layer through hr_fuse.hip alone (op-level parity tests): out = act(base + sum_s up_{2^shift_s}(W_s x_s + b_s)),
+// terms added in the order given.  base / x_s device fp32 NHWC; f16 != 0 runs the fp16 instantiation on fp16 copies of them and `out` receives
+// fp16 rows (else fp32).  Weights [C][C_s] and biases [C] on the host.
+extern "C" int hmv_op_hr_fuse_up(int32_t device, int32_t f16, const float *base, int32_t N, int32_t H, int32_t W, int32_t C, int32_t nsrc,
+                                 const float *const *src, const int32_t *src_c, const int32_t *shift, const float *const *w_host,
+                                 const float *const *bias_host, int32_t relu, void *out, void *stream) {
+    if (!base || !out || !src || !src_c || !shift || !w_host || !bias_host || nsrc < 1 || nsrc > 3 || N <= 0 || H <= 0 || W <= 0 || C <= 0) {
+        g_create_err = "hmv_op_hr_fuse_up: bad arguments";
+        return HMV_ERR_ARG;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HrFuseParams p{};
+    p.N = N; p.H = H; p.W = W; p.C = C; p.ldc = C; p.nsrc = nsrc; p.relu = relu ? 1 : 0; p.f16 = f16 ? 1 : 0;
+    std::vector<void *> owned;
+    auto fail = [&](int rc, const std::string &msg) {
+        for (void *q : owned) (void)hipFree(q);
+        g_create_err = "hmv_op_hr_fuse_up: " + msg;
+        return rc;
+    };
+    hipError_t e = hipSuccess;
+    auto dev_copy = [&](const std::vector<float> &v) -> float * {
+        void *d = nullptr;
+        if (e == hipSuccess) e = hipMalloc(&d, v.size() * sizeof(float));
+        if (e == hipSuccess) { owned.push_back(d); e = hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice); }
+        return static_cast<float *>(d);
+    };
+    auto as_half = [&](const float *x, size_t rows, int ch) -> const void * {   // fp16 copy of fp32 rows
+        void *d = nullptr;
+        if (e == hipSuccess) e = hipMalloc(&d, rows * ch * 2);
+        if (e == hipSuccess) { owned.push_back(d); e = launch_rows_f32_to_half(x, d, rows, ch, 1, s); }
+        return d;
+    };
+    for (int q = 0; q < nsrc; ++q) {
+        HrFuseSrc &S = p.src[q];
+        if (!src[q] || !w_host[q] || !bias_host[q] || src_c[q] <= 0 || shift[q] < 1 || shift[q] > 3) return fail(HMV_ERR_ARG, "bad source");
+        S.C = src_c[q]; S.ld = src_c[q]; S.shift = shift[q]; S.H = H >> shift[q]; S.W = W >> shift[q];
+        S.ldw = round_up(src_c[q], 32);
+        std::vector<float> wp((size_t)round_up(C, 16) * S.ldw, 0.f), bp((size_t)round_up(C, 16), 0.f);   // rows / columns past C and C_s are zeros
+        for (int o = 0; o < C; ++o) {
+            for (int k = 0; k < S.C; ++k) wp[(size_t)o * S.ldw + k] = w_host[q][(size_t)o * S.C + k];
+            bp[o] = bias_host[q][o];
+        }
+        S.w = dev_copy(wp);
+        S.bias = dev_copy(bp);
+        S.x = f16 ? as_half(src[q], (size_t)N * S.H * S.W, S.C) : static_cast<const void *>(src[q]);
+    }
+    p.base = f16 ? as_half(base, (size_t)N * H * W, C) : static_cast<const void *>(base);
+    p.out = out;
+    if (e != hipSuccess) return fail(HMV_ERR_HIP, hipGetErrorString(e));
+    if (!hr_fuse_up_plan(p)) return fail(HMV_ERR_ARG, "the shape has no fused form (C % 4 (fp16: 8), C_s % 16, exact 2^shift map sizes, LDS)");
+    e = launch_hr_fuse_up(p, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(HMV_ERR_HIP, hipGetErrorString(e));
+    for (void *q : owned) (void)hipFree(q);
+    return HMV_OK;
+}
+
 // One fp32 3x3 stride-1 pad-1 conv C -> C in the ROW-DECOMPOSED packing (Loader::conv, rd) through Runner::conv: what HRNet-w40's 40- /
 // 80-channel branches run.  kernel_sel: 0 the launcher's choice, 1 conv_igemm's row-decomposed tiles, 2 conv_rds.hip whatever the size
 extern "C" int hmv_op_conv2d_rd(int32_t device, const float *in, int32_t N, int32_t H, int32_t W, int32_t C, const float *w_oihw,

@@ -226,6 +226,15 @@ int hmv_op_conv2d_f16(int32_t device, const float *in, int32_t N, int32_t H, int
                       int32_t pad, const float *residual, int32_t relu, void *out_f16, int32_t kernel_sel,
                       const char **kernel_name, void *stream);
 
+/* The up-sampling terms of an HRNet fuse layer (hrnet.py:194-212) through hr_fuse.hip alone (op-level parity tests):
+ *   out = act(base + sum_s Upsample_{2^shift_s, nearest}(W_s x_s + b_s)),   terms added in the order given (1 <= nsrc <= 3, 1 <= shift <= 3).
+ * base [N][H][W][C] and src[s] [N][H >> shift_s][W >> shift_s][src_c[s]]: device fp32 NHWC; w_host[s] [C][src_c[s]] and bias_host[s] [C] on
+ * the host.  f16 != 0: the fp16 instantiation on fp16 copies of base / src, `out` receives fp16 rows; else fp32 rows.  HMV_ERR_ARG for
+ * shapes without a fused form (C % 4 -- fp16: 8 --, src_c % 16, map sizes that are not exact multiples of 2^shift). */
+int hmv_op_hr_fuse_up(int32_t device, int32_t f16, const float *base, int32_t N, int32_t H, int32_t W, int32_t C, int32_t nsrc,
+                      const float *const *src, const int32_t *src_c, const int32_t *shift, const float *const *weight_host,
+                      const float *const *bias_host, int32_t relu, void *out, void *stream);
+
 /* One multi-head attention of the fusion transformer (layers.py:216-221; 8 heads x 128) through the engine's kernel
  * (op-level parity tests).  qkv device [B][T][3 * 1024] = [q | k | v] per token; queries are tokens [0, Tq), keys / values
  * tokens [koff, koff + Tk); out device [B][Tq][1024]. */

@@ -877,6 +877,68 @@ def test_chained_launches_give_the_bits_of_one_launch_per_conv(case, frames_per_
     m.set_chain_fusion(True)
 
 
+# hr_fuse.hip alone: (N, H, W, C, [(C_s, shift_s), ...], relu) -- whole and ragged 16 x 32 tiles, one to three sources, HRNet-w40's and
+# w64's channel counts (40 = 2.5 sixteen-channel blocks; 128 / 512-channel sources take the 8-row tiles in fp32), maps smaller than a tile
+HRF_SHAPES = [(2, 16, 32, 40, [(80, 1), (160, 2), (320, 3)], True), (3, 24, 40, 40, [(80, 1), (160, 2), (320, 3)], True),
+              (1, 8, 8, 80, [(160, 1), (320, 2)], True), (2, 16, 16, 64, [(128, 1), (256, 2), (512, 3)], True),
+              (1, 8, 16, 128, [(256, 1), (512, 2)], False), (2, 48, 64, 48, [(96, 1)], True), (5, 32, 32, 40, [(80, 1), (160, 2)], False)]
+
+
+@pytest.mark.parametrize("shape", HRF_SHAPES)
+@pytest.mark.parametrize("f16", [0, 1])
+def test_hr_fuse_up_vs_torch(shape, f16):
+    """The fused up-sampling terms of an HRNet fuse layer (hrnet.py:194-212) through hmv_op_hr_fuse_up against torch in float64:
+    out = act(base + sum_s nearest_up_{2^shift}(conv1x1(x_s) + b_s)), terms added in order.  fp32: exact-fp32 MFMA products, 1e-5 of the
+    output scale; fp16: the same arithmetic on fp16-rounded inputs with ONE rounding of the result (1e-3)."""
+    from handmvnet_amd import _lib
+    lib = _lib.load()
+    N, H, W, C, srcs, relu = shape
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W + C)
+    dev = torch.device("cuda:0")
+    base = torch.randn(N, H, W, C, generator=g)
+    xs = [torch.randn(N, H >> sh, W >> sh, cs, generator=g) for cs, sh in srcs]
+    ws = [torch.randn(C, cs, generator=g) / cs ** 0.5 for cs, _ in srcs]
+    bs = [torch.randn(C, generator=g) for _ in srcs]
+    rnd = (lambda t: t.half().double()) if f16 else (lambda t: t.double())
+    ref = rnd(base)
+    for x, w, b, (_, sh) in zip(xs, ws, bs, srcs):
+        gq = rnd(x) @ w.double().t() + b.double()
+        ref = ref + gq.repeat_interleave(1 << sh, dim=1).repeat_interleave(1 << sh, dim=2)
+    if relu:
+        ref = ref.clamp_min(0)
+    dbase = base.to(dev)
+    dxs = [x.contiguous().to(dev) for x in xs]
+    out = torch.full((N, H, W, C), float("nan"), device=dev, dtype=torch.float16 if f16 else torch.float32)
+    n = len(srcs)
+    vp = ctypes.c_void_p
+    src_p = (vp * n)(*[vp(t.data_ptr()) for t in dxs])
+    wn = [w.contiguous().numpy() for w in ws]
+    bn = [b.contiguous().numpy() for b in bs]
+    w_p = (vp * n)(*[a.ctypes.data_as(vp) for a in wn])
+    b_p = (vp * n)(*[a.ctypes.data_as(vp) for a in bn])
+    cs_a = (ctypes.c_int32 * n)(*[cs for cs, _ in srcs])
+    sh_a = (ctypes.c_int32 * n)(*[sh for _, sh in srcs])
+    rc = lib.hmv_op_hr_fuse_up(0, f16, vp(dbase.data_ptr()), N, H, W, C, n, src_p, cs_a, sh_a, w_p, b_p, int(relu), vp(out.data_ptr()), None)
+    assert rc == 0, lib.hmv_last_error(None)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (1e-3 if f16 else 1e-5), err
+
+
+def test_hr_fuse_up_refuses_shapes_without_a_fused_form():
+    from handmvnet_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    vp = ctypes.c_void_p
+    base, x = torch.zeros(1, 10, 16, 40, device=dev), torch.zeros(1, 2, 4, 80, device=dev)     # 10 rows are not a multiple of 2^2
+    w, b = np.zeros((40, 80), np.float32), np.zeros(40, np.float32)
+    out = torch.zeros(1, 10, 16, 40, device=dev)
+    rc = lib.hmv_op_hr_fuse_up(0, 0, vp(base.data_ptr()), 1, 10, 16, 40, 1, (vp * 1)(vp(x.data_ptr())), (ctypes.c_int32 * 1)(80), (ctypes.c_int32 * 1)(2),
+                               (vp * 1)(w.ctypes.data_as(vp)), (vp * 1)(b.ctypes.data_as(vp)), 1, vp(out.data_ptr()), None)
+    assert rc != 0 and b"fused form" in lib.hmv_last_error(None)
+
+
 @pytest.mark.parametrize("case,size,nb", [("hr40_v4_128", 128, 2), ("hr40_v4_128", 256, 3), ("hr40_v4_128", 96, 2), ("hr64_tiny", 64, 2), ("hr64_tiny", 160, 1)])
 @pytest.mark.parametrize("mode", ["f32", "f16"])
 def test_hrnet_fuse_layers_in_one_launch(case, size, nb, mode):

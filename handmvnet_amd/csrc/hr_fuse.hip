@@ -203,6 +203,8 @@ __global__ __launch_bounds__(64 * HRF_WAVES) void hr_fuse_up_kernel(const HrFuse
 // ====================================================================== host side
 // Fills the tile height, the LDS layout and the item lists; false: the shape has no fused form (the caller runs the per-term launches)
 bool hr_fuse_up_plan(HrFuseParams &p) {
+    p.th = 0;
+    p.lds = 0;
     if (p.nsrc < 1 || p.nsrc > 3 || p.C % (p.f16 ? 8 : 4) || p.C > 256 || p.ldc % 4 || p.N <= 0 || p.H <= 0 || p.W <= 0) return false;
     if ((long long)p.H * p.W * p.ldc >= (1ll << 31) || p.C < 8) return false;   // 32-bit element offsets inside an image
     const int esz = p.f16 ? 2 : 4;

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("HMV_LIB") or os.path.join(_HERE, "libhandmv.so")   # 
 SYMBOLS = ["hmv_create", "hmv_set_tensor", "hmv_finalize_weights", "hmv_workspace_bytes", "hmv_reserve", "hmv_forward",
            "hmv_last_error", "hmv_destroy", "hmv_set_capture", "hmv_read_stage", "hmv_set_profiling", "hmv_profile_count",
            "hmv_profile_get", "hmv_op_conv2d", "hmv_op_conv2d_ex", "hmv_op_conv2d_f16", "hmv_op_conv2d_sel", "hmv_op_conv2d_rd", "hmv_op_attention", "hmv_op_attention_lq", "hmv_bench_conv", "hmv_pose_metrics", "hmv_forward_frames",
-           "hmv_op_prepare_frames", "hmv_set_graphs", "hmv_graph_stats", "hmv_version", "hmv_tile_rule", "hmv_profile_get_bytes", "hmv_poison_workspace", "hmv_launch_count", "hmv_set_tail_fusion", "hmv_set_chain_fusion", "hmv_set_hr_fusion", "hmv_set_x3k16_mode", "hmv_op_hr_fuse_up"]
+           "hmv_op_prepare_frames", "hmv_set_graphs", "hmv_graph_stats", "hmv_version", "hmv_tile_rule", "hmv_profile_get_bytes", "hmv_poison_workspace", "hmv_launch_count", "hmv_set_tail_fusion", "hmv_set_chain_fusion", "hmv_set_hr_fusion", "hmv_set_x3k16_mode", "hmv_op_hr_fuse_up", "hmv_op_attention_x3"]
 
 HMV_OK = 0
 
@@ -80,6 +80,7 @@ def load() -> ctypes.CDLL:
     lib.hmv_op_attention_lq.argtypes = [ci, fp, ci, ci, fp, fp, ci, ci, ci, ci, fp, vp]
     lib.hmv_op_attention_lq.restype = ctypes.c_int
     lib.hmv_op_attention.argtypes = [ci, fp, ci, ci, ci, ci, ci, fp, vp]
+    lib.hmv_op_attention_x3.argtypes = [ci, fp, ci, ci, ci, ci, ci, fp, vp]
     lib.hmv_op_hr_fuse_up.argtypes = [ci, ci, fp, ci, ci, ci, ci, ci, ctypes.POINTER(vp), ctypes.POINTER(ci), ctypes.POINTER(ci),
                                       ctypes.POINTER(vp), ctypes.POINTER(vp), ci, vp, vp]
     lib.hmv_op_attention.restype = ctypes.c_int

@@ -1881,7 +1881,12 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         float *att = R.alloc((size_t)qrows * INNER);
         // fp16-kernel modes, fused tail: the attention rows leave the kernel as (hi, lo) pairs and to_out is a split-pair GEMM
         const bool tx3 = a.out_x3.plane != 0 && R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt, true);
-        if (Tk > 0) LAUNCH(launch_attention(qkv, B, Tcur, Tq, koff, Tk, att, s, tx3 ? 1 : 0));
+#ifdef HMV_NO_ATT_X3   // A/B builds only (python -m handmvnet_amd.build --variant noax HMV_NO_ATT_X3): the exact-fp32 attention in every mode
+        const int att_x3 = 0;
+#else
+        const int att_x3 = h16 ? 1 : 0;   // fp16-kernel modes: q, k, v, P as (hi, lo) pairs on the fp16 matrix cores (by the arithmetic mode alone)
+#endif
+        if (Tk > 0) LAUNCH(launch_attention(qkv, B, Tcur, Tq, koff, Tk, att, s, tx3 ? 1 : 0, att_x3));
         else LAUNCH(hipMemsetAsync(att, 0, (size_t)qrows * INNER * sizeof(float), s));   // (zero rows are zero pairs)
         R.release(qkv);
         if (R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt, tx3)) {   // norm1(to_out + _q) -> FeedForward -> norm2 in one launch behind the GEMM
@@ -2273,6 +2278,18 @@ int hmv_op_attention(int32_t device, const float *qkv, int32_t B, int32_t T, int
     }
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
     const hipError_t e = launch_attention(qkv, B, T, Tq, koff, Tk, out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) { g_create_err = std::string("attention launch failed: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
+    return HMV_OK;
+}
+
+int hmv_op_attention_x3(int32_t device, const float *qkv, int32_t B, int32_t T, int32_t Tq, int32_t koff, int32_t Tk, float *out,
+                        void *stream) {
+    if (!qkv || !out || B <= 0 || T <= 0 || Tq <= 0 || Tq > T || Tk <= 0 || koff < 0 || koff + Tk > T) {
+        g_create_err = "hmv_op_attention_x3: bad argument";
+        return HMV_ERR_ARG;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
+    const hipError_t e = launch_attention(qkv, B, T, Tq, koff, Tk, out, static_cast<hipStream_t>(stream), 0, 1);
     if (e != hipSuccess) { g_create_err = std::string("attention launch failed: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
     return HMV_OK;
 }

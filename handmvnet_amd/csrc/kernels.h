@@ -153,7 +153,8 @@ hipError_t launch_tokens_finalize(float *tokens, int ldt, int d, int fdim, int N
 hipError_t launch_layernorm(const float *x, int ldx, int rows, int d, const float *g1, const float *b1, float *y,
                             int ldy, const float *g2, const float *b2, float *y2, hipStream_t s);
 // softmax(q k^T / sqrt(128)) v per (sample, head); qkv rows are [q | k | v] of width 3*1024.
-hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s, int pairs = 0);   // pairs: the rows as (hi, lo) fp16 pairs [hi 1024 | lo 1024] instead of fp32
+hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s, int pairs = 0, int x3 = 0);
+// (x3: the fp16-kernel modes' form -- every operand as fp16 (hi, lo) pairs on the fp16 matrix cores, fp32-equivalent: attention_x3_kernel)   // pairs: the rows as (hi, lo) fp16 pairs [hi 1024 | lo 1024] instead of fp32
 // MultiHeadAttentionLearnableQuery (layers.py:240-301): softmax(q k^T / sqrt(256)) v per (sample, head), 8 heads x 256.
 // q rows: q + (b * q_bstride + i) * q_ld (q_bstride = 0: the same 21 probe queries for every sample); k / v rows:
 // k + (b * T + j) * kv_ld, j < T.  out [B*Tq][2048].

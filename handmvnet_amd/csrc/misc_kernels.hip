@@ -901,6 +901,231 @@ __global__ __launch_bounds__(64 * ATT_WAVES, D == 128 ? HMV_ATT_OCC : 1) void at
         }
     }
 }
+// ------------------------------------------------------------------ attention on the fp16 matrix cores over (hi, lo) pairs (round 4)
+// The fp16-kernel modes' form of attention_mfma_kernel<128>: same decomposition (one workgroup per (sample, head, 32-query block), the
+// 32-key chunks dealt to four waves, S^T = K Q^T so that a query row is a lane, P stays in registers, partials merged through LDS in
+// wave order), but both products run on v_mfma_f32_32x32x16_f16 with every operand split into fp16 (hi, lo) pairs, hi = fp16(x),
+// lo = fp16(x - hi), and three MFMAs per k16 step -- hi.hi + lo.hi + hi.lo, fp32 accumulation: fp32-equivalent (2^-22 per operand) like
+// the q / k / v projections in front of it (gemm_x3.hip) at 8 + 8 instead of 64 + 64 matrix-pipe cycles per 16 channels / keys.  The
+// exact-fp32 kernel spends 41 of its 88 us at cfg-3 in the matrix pipe (tools/att_probe.py).
+//   S^T   A = K rows (the lane's own key row from global memory, split in registers), B = Q block from LDS, split once per workgroup
+//         and stored in operand order: slot j of lane (q, kh) at step u = channel 16 u + 8 (j >> 2) + 4 kh + (j & 3) for BOTH operands
+//   P V   B = P^T straight from the accumulator registers (slot j of step s = register 8 s + j = key 16 s + 8 (j >> 2) + 4 kh + (j & 3)),
+//         A = V^T: the 16 keys of a step sit row-major [key][channel] in a per-wave LDS buffer (split on the way in) and come back
+//         column-major through ds_read_b64_tr_b16 -- lane 4 q + p of a 16-lane group supplies the address of row q, channels 4 p .. 4 p + 3,
+//         lane i receives channel i of the four rows -- two reads per operand (keys 4 kh + 0 .. 3 and 8 + 4 kh + 0 .. 3).  Row stride
+//         320 bytes: the eight 32-byte row pieces of a 32-lane half fall on distinct banks.
+typedef __fp16 atr4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+constexpr int AX_QLD = 136, AX_VLD = 160;                      // halfs per Q row (272 B) / V row (320 B) in LDS
+constexpr int AX_Q_HALFS = 2 * 32 * AX_QLD, AX_V_HALFS = 2 * 16 * AX_VLD;   // [plane][32 queries] ; per wave [plane][16 keys]
+constexpr int AX_WAVES = 4;
+constexpr int AX_LOOP_BYTES = (AX_Q_HALFS + AX_WAVES * AX_V_HALFS) * 2;
+constexpr int AX_MERGE_BYTES = (AX_WAVES * 4 * 16 * 64 + 2 * AX_WAVES * 32) * 4;
+constexpr int AX_LDS_BYTES = AX_LOOP_BYTES > AX_MERGE_BYTES ? AX_LOOP_BYTES : AX_MERGE_BYTES;
+
+// split_f16 on four values (the clamp as ONE v_med3_f32: fminf / fmaxf canonicalise their operands first; same result for finite inputs)
+__device__ __forceinline__ void ax_split4(const f32x4 v, f16x4 &hi, f16x4 &lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float c = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+        hi[e] = (_Float16)c;
+        lo[e] = (_Float16)(c - (float)hi[e]);
+    }
+}
+__device__ __forceinline__ f16x8 ax_cat(const f16x4 a, const f16x4 b) { return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+
+__global__ __launch_bounds__(64 * AX_WAVES, 2) void attention_x3_kernel(const float *__restrict__ q, int q_ld, int q_bstride,
+        const float *__restrict__ k, const float *__restrict__ v, int kv_ld, int T, int Tq, int Tk, int nqb, float *__restrict__ out, int pairs) {
+    constexpr int D = 128, NC = 4, NU = 16;
+    extern __shared__ __attribute__((aligned(16))) char ax_smem[];
+    const int qblk = blockIdx.x % nqb, bh = blockIdx.x / nqb;
+    const int b = bh >> 3, h = bh & 7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const size_t ld = (size_t)kv_ld;
+    const float *qb = q + (size_t)b * q_bstride * q_ld + h * D;
+    const float *kb = k + (size_t)b * T * ld + h * D, *vb = v + (size_t)b * T * ld + h * D;
+    const int nkc = (Tk + 31) >> 5;
+    const float scale = 0.08838834764831845f;   // 128 ** -0.5
+    _Float16 *sQ = reinterpret_cast<_Float16 *>(ax_smem);                                   // [2][32][AX_QLD]
+    _Float16 *sVw = sQ + AX_Q_HALFS + wave * AX_V_HALFS;                                    // [2][16][AX_VLD], this wave's
+
+    f32x4 kf[NU], v0[8];   // the chunk's key rows; 16 of its value rows (16 keys x 128 channels = 8 vectors per lane)
+    int kc = wave;
+    // (keys >= Tk read the last valid row: their logits are set to -inf and their P to exactly 0 below, so only finiteness matters)
+#define AX_LOAD_K(KC)                                                                                   \
+    do {                                                                                                \
+        const float *krow_ = kb + (size_t)min((KC) * 32 + l31, Tk - 1) * ld + 4 * kh;                   \
+        _Pragma("unroll") for (int u = 0; u < NU; ++u) kf[u] = *reinterpret_cast<const f32x4 *>(krow_ + 8 * u); \
+    } while (0)
+#define AX_LOAD_V(KEY0, VR)                                                                             \
+    do {                                                                                                \
+        _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                              \
+            const int k2_ = min((KEY0) + 2 * it + kh, Tk - 1);   /* unit it * 64 + lane = key 2 it + (lane >> 5), channels 4 (lane & 31) .. */ \
+            VR[it] = *reinterpret_cast<const f32x4 *>(vb + (size_t)k2_ * ld + 4 * l31);                 \
+        }                                                                                               \
+    } while (0)
+    // 16 keys -> the wave's LDS buffer as (hi, lo) halfs, row-major
+#define AX_STORE_V(VR)                                                                                  \
+    do {                                                                                                \
+        __builtin_amdgcn_wave_barrier();                                                                \
+        _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                              \
+            f16x4 hi_, lo_;                                                                             \
+            ax_split4(VR[it], hi_, lo_);                                                                \
+            *reinterpret_cast<f16x4 *>(&sVw[(2 * it + kh) * AX_VLD + 4 * l31]) = hi_;                   \
+            *reinterpret_cast<f16x4 *>(&sVw[(16 + 2 * it + kh) * AX_VLD + 4 * l31]) = lo_;              \
+        }                                                                                               \
+        __builtin_amdgcn_wave_barrier();                                                                \
+    } while (0)
+    // O^T += V^T P^T over the 16 keys of step S_: per 32-channel block two transposed reads per plane, three MFMAs
+#define AX_PV(S_)                                                                                       \
+    do {                                                                                                \
+        _Pragma("unroll") for (int c = 0; c < NC; ++c) {                                                \
+            const _Float16 *t0 = sVw + (4 * kh + ((lane & 15) >> 2)) * AX_VLD + 32 * c + 16 * ((lane >> 4) & 1) + 4 * (lane & 3); \
+            const f16x4 h0 = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) atr4 *)(t0))); \
+            const f16x4 h1 = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) atr4 *)(t0 + 8 * AX_VLD))); \
+            const f16x4 l0 = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) atr4 *)(t0 + 16 * AX_VLD))); \
+            const f16x4 l1 = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) atr4 *)(t0 + 24 * AX_VLD))); \
+            const f16x8 ah_ = ax_cat(h0, h1), al_ = ax_cat(l0, l1);                                     \
+            o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, ph[S_], o[c], 0, 0, 0);                  \
+            o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, ph[S_], o[c], 0, 0, 0);                  \
+            o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, pl[S_], o[c], 0, 0, 0);                  \
+            if (c & 1) __builtin_amdgcn_sched_barrier(0);   /* (two blocks' operands in flight at a time: registers) */ \
+        }                                                                                               \
+    } while (0)
+    if (kc < nkc) {
+        AX_LOAD_K(kc);
+        AX_LOAD_V(kc * 32, v0);
+    }
+    // Q block (rows >= Tq are zeros) -> (hi, lo) halfs in operand order, shared by the waves
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = it * 256 + tid, r = idx >> 5, c = 4 * (idx & 31), row = qblk * 32 + r;
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+        if (row < Tq) qv = *reinterpret_cast<const f32x4 *>(qb + (size_t)row * q_ld + c);
+        f16x4 hi_, lo_;
+        ax_split4(qv, hi_, lo_);
+        const int pos = (c >> 4) * 16 + ((c >> 2) & 1) * 8 + ((c >> 3) & 1) * 4;   // step, k-half, first or second group of four
+        *reinterpret_cast<f16x4 *>(&sQ[r * AX_QLD + pos]) = hi_;
+        *reinterpret_cast<f16x4 *>(&sQ[(32 + r) * AX_QLD + pos]) = lo_;
+    }
+    __syncthreads();
+
+    f32x16 o[NC];   // o[c][e] on lane (q, half): O[q][32c + (e&3) + 8(e>>2) + 4 half]
+    float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[c][e] = 0.f;
+
+    for (; kc < nkc; kc += AX_WAVES) {
+        f32x16 sacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            f16x4 a0h, a0l, a1h, a1l;
+            ax_split4(kf[2 * u], a0h, a0l);
+            ax_split4(kf[2 * u + 1], a1h, a1l);
+            const f16x8 ah = ax_cat(a0h, a1h), al = ax_cat(a0l, a1l);
+            const f16x8 bh_ = *reinterpret_cast<const f16x8 *>(&sQ[l31 * AX_QLD + u * 16 + kh * 8]);
+            const f16x8 bl_ = *reinterpret_cast<const f16x8 *>(&sQ[(32 + l31) * AX_QLD + u * 16 + kh * 8]);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh_, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh_, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl_, sacc, 0, 0, 0);
+            if (u & 1) __builtin_amdgcn_sched_barrier(0);   // (two steps' operands at a time: the splits of all eight would not fit the registers)
+        }
+        // the key rows of this wave's NEXT chunk fly during the softmax and the P V products of this one (their registers are free)
+        if (kc + AX_WAVES < nkc) AX_LOAD_K(kc + AX_WAVES);
+        // register e = key (e&3) + 8(e>>2) + 4 half of the chunk, for query l31
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool kv_ = kc * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh < Tk;
+            sacc[e] = kv_ ? sacc[e] * scale : -INFINITY;
+            mx = fmaxf(mx, sacc[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // finite: the chunk has >= 1 valid key
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);         // exp(-inf) = 0 on the first chunk
+        float psum = 0.f;
+        f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pe = expf(sacc[e] - m_new);      // exp(-inf) = 0 for keys >= Tk
+            psum += pe;
+            const _Float16 a = (_Float16)pe;               // 0 <= pe <= 1: no clamp
+            ph[e >> 3][e & 7] = a;
+            pl[e >> 3][e & 7] = (_Float16)(pe - (float)a);
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[c][e] *= alpha;
+        AX_STORE_V(v0);
+        AX_LOAD_V(kc * 32 + 16, v0);          // the second 16 value rows fly under the first 16 keys' products
+        AX_PV(0);
+        AX_STORE_V(v0);
+        if (kc + AX_WAVES < nkc) AX_LOAD_V((kc + AX_WAVES) * 32, v0);   // ... and the next chunk's first 16 value rows under the second
+        AX_PV(1);
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef AX_LOAD_K
+#undef AX_LOAD_V
+#undef AX_STORE_V
+#undef AX_PV
+
+    // ---- merge the 4 waves' partials in wave order (attention_mfma_kernel's): out = sum_w O_w e^(m_w - M) / sum_w l_w e^(m_w - M)
+    __syncthreads();   // the merge area aliases the loop's buffers
+    float *att_smem = reinterpret_cast<float *>(ax_smem);
+    float *sO = att_smem, *sM = att_smem + AX_WAVES * NC * 16 * 64, *sL = sM + AX_WAVES * 32;
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (kh == 0) { sM[wave * 32 + l31] = m_run; sL[wave * 32 + l31] = l_run; }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sO[((wave * NC + c) * 16 + e) * 64 + lane] = o[c][e];
+    __syncthreads();
+    {
+        float M = sM[l31];
+#pragma unroll
+        for (int w = 1; w < AX_WAVES; ++w) M = fmaxf(M, sM[w * 32 + l31]);
+        float a[AX_WAVES], den = 0.f;
+#pragma unroll
+        for (int w = 0; w < AX_WAVES; ++w) {
+            a[w] = expf(sM[w * 32 + l31] - M);   // exp(-inf) = 0 for a wave that had no chunk
+            den += sL[w * 32 + l31] * a[w];
+        }
+        const float inv = 1.f / den;
+        const int row = qblk * 32 + l31;
+        const int c = wave;   // this wave finishes channel block `wave`
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 r4;
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                float num = 0.f;
+#pragma unroll
+                for (int w = 0; w < AX_WAVES; ++w) num += sO[((w * NC + c) * 16 + 4 * g + e2) * 64 + lane] * a[w];
+                r4[e2] = num * inv;
+            }
+            if (row < Tq) {
+                if (pairs) {
+                    f16x4 hi4, lo4;
+                    ax_split4(r4, hi4, lo4);
+                    _Float16 *pr = reinterpret_cast<_Float16 *>(out) + ((size_t)b * Tq + row) * (16 * D) + h * D + 32 * c + 8 * g + 4 * kh;
+                    *reinterpret_cast<f16x4 *>(pr) = hi4;
+                    *reinterpret_cast<f16x4 *>(pr + 8 * D) = lo4;
+                } else {
+                    *reinterpret_cast<f32x4 *>(out + ((size_t)b * Tq + row) * (8 * D) + h * D + 32 * c + 8 * g + 4 * kh) = r4;
+                }
+            }
+        }
+    }
+}
+
 template <int D, int W>
 static hipError_t launch_attention_w(const float *q, int q_ld, int q_bstride, const float *k, const float *v, int kv_ld, int B, int T, int Tq,
                                      int Tk, float *out, hipStream_t s, int pairs, int nqb) {
@@ -927,7 +1152,22 @@ static hipError_t launch_attention_any(const float *q, int q_ld, int q_bstride, 
     // plus the latencies two waves per SIMD cannot hide, not by the split)
     return launch_attention_w<D, 4>(q, q_ld, q_bstride, k, v, kv_ld, B, T, Tq, Tk, out, s, pairs, nqb);
 }
-hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s, int pairs) {
+hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s, int pairs, int x3) {
+    if (x3) {   // the fp16-kernel modes: (hi, lo) operands on the fp16 matrix cores (attention_x3_kernel); by the arithmetic mode alone, never by a size
+        if (Tk <= 0 || Tq <= 0 || B <= 0) return hipErrorInvalidValue;
+        static bool configured[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!configured[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attention_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, AX_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            configured[dev] = true;
+        }
+        const int nqb = (Tq + 31) >> 5;
+        hipLaunchKernelGGL(attention_x3_kernel, dim3((unsigned)B * 8 * nqb), dim3(64 * AX_WAVES), AX_LDS_BYTES, s, qkv, 3 * 1024, T,
+                           qkv + (size_t)koff * 3072 + 1024, qkv + (size_t)koff * 3072 + 2048, 3 * 1024, T, Tq, Tk, nqb, out, pairs);
+        return hipGetLastError();
+    }
     return launch_attention_any<128>(qkv, 3 * 1024, T, qkv + (size_t)koff * 3072 + 1024, qkv + (size_t)koff * 3072 + 2048, 3 * 1024, B, T, Tq, Tk, out, s, pairs);
 }
 

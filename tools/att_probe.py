@@ -12,6 +12,7 @@ from handmvnet_amd import _lib  # noqa: E402
 
 def main():
     lib = _lib.load()
+    op = lib.hmv_op_attention_x3 if "--x3" in sys.argv else lib.hmv_op_attention   # --x3: the fp16-kernel modes' (hi, lo) form
     dev = torch.device("cuda:0")
     for (B, T, Tq, koff, Tk) in ((32, 168, 168, 0, 168), (32, 168, 21, 0, 168), (32, 21, 21, 0, 21), (1, 168, 168, 0, 168), (32, 273, 273, 0, 273)):
         g = torch.Generator(device="cpu").manual_seed(1)
@@ -19,14 +20,14 @@ def main():
         out = torch.empty(B, Tq, 1024, device=dev)
         s = torch.cuda.current_stream().cuda_stream
         for _ in range(5):
-            rc = lib.hmv_op_attention(0, ctypes.c_void_p(qkv.data_ptr()), B, T, Tq, koff, Tk, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(s))
+            rc = op(0, ctypes.c_void_p(qkv.data_ptr()), B, T, Tq, koff, Tk, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(s))
             assert rc == 0
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 50
         e0.record()
         for _ in range(n):
-            lib.hmv_op_attention(0, ctypes.c_void_p(qkv.data_ptr()), B, T, Tq, koff, Tk, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(s))
+            op(0, ctypes.c_void_p(qkv.data_ptr()), B, T, Tq, koff, Tk, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(s))
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n

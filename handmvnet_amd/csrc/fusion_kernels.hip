@@ -43,11 +43,11 @@ constexpr int FF_WAVES = 8;          // a workgroup takes 16 RB token rows, RB =
 // registers allow -- ahead of the LayerNorm phase for the first GEMM -- and the block is then 4 nv back-to-back MFMAs (wmma): a
 // launch-bound kernel must not pay an L2 round trip per 64 columns.  Two accumulators alternate (issue-bound, not latency-bound).
 template <int NV>
-__device__ __forceinline__ void wload(ff32x4 (&b)[NV], const float *w, int ldw, int nv, int lane) {
+__device__ __forceinline__ void wload(ff32x4 (&b)[NV], const float *w, int ldw, int nv, int lane, int first = 0, int last = NV) {
     const float *wp = w + (size_t)(lane & 15) * ldw + 4 * (lane >> 4);
 #pragma unroll
     for (int s = 0; s < NV; ++s)
-        if (s < nv) b[s] = *reinterpret_cast<const ff32x4 *>(wp + 16 * s);
+        if (s >= first && s < last && s < nv) b[s] = *reinterpret_cast<const ff32x4 *>(wp + 16 * s);
 }
 template <int NV>
 __device__ __forceinline__ ff32x4 wmma(const float *sa, int lda, const ff32x4 (&b)[NV], int nv, int lane) {
@@ -65,6 +65,7 @@ __device__ __forceinline__ ff32x4 wmma(const float *sa, int lda, const ff32x4 (&
     return acc0 + acc1;   // lane holds D[4 g + e][r], e = 0..3
 }
 constexpr int FF_NV1 = 36;   // ld <= 576: the 16-wide steps of the first GEMM's reduction
+constexpr int FF_W1A = 8;    // ... of which this many are requested at kernel entry, the rest behind the first row loads of phase 0
 constexpr int FF_NV2 = 16;   // hid <= 256
 
 // A lane owns the 16-byte column groups c = 4 lane + 256 i (+ 0..3), i < FF_VEC: rows move as 16-byte vectors (a third of the
@@ -132,7 +133,9 @@ __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockPa
     // nothing below depends on the activations: requested first, in flight while the rows are assembled and normalised
     ff32x4 wv1[FF_NV1];
     const int nv1 = p.ld >> 4, nblk2 = p.ld >> 4;
-    wload(wv1, p.w1 + (size_t)wave * 16 * p.ldw1, p.ldw1, nv1, lane);
+    // (round 4: only the first FF_W1A steps here -- vector-memory returns are in order per wave, and the rows' own loads of phase 0 would
+    // otherwise wait behind all 35 KB of this wave's weight vectors; the rest goes out once the first row pair's loads are on their way)
+    wload(wv1, p.w1 + (size_t)wave * 16 * p.ldw1, p.ldw1, nv1, lane, 0, FF_W1A);
     // the three LayerNorms' gamma / beta, staged once per workgroup: [4][ld] over the sH region, LayerNorm2's [2][ld] behind it
     float *sP = sH, *sP2 = sH + hreg;
     {
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(64 * FF_WAVES) void ff_block_kernel(const FfBlockPa
                 for (int e = 0; e < 4; ++e) v[r][i][e] = (c + e) < p.d ? t[e] : 0.f;
             }
         }
+        if (rp == 0) wload(wv1, p.w1 + (size_t)wave * 16 * p.ldw1, p.ldw1, nv1, lane, FF_W1A, FF_NV1);   // (behind the first row pair's loads)
         if (p.n1g) ln_rows2(v, p.d, lane, sP, sP + p.ld);
 #pragma unroll
         for (int r = 0; r < 2; ++r)

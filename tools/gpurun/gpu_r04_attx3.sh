@@ -1,11 +1,13 @@
 # round 4: attention on the fp16 matrix cores over (hi, lo) pairs (attention_x3_kernel) in the fp16-kernel modes: op-level and network tests,
-# launch times beside the fp32 kernel, same-box A/B of the fp16 / f32x3 steps against build/libhandmv_noax.so (the fp32-MFMA attention there)
+# launch times beside the fp32 kernel, same-box A/B of the fp16 / f32x3 / batch-1 steps against build/libhandmv_noax.so
+# (python -m handmvnet_amd.build --variant noax HMV_NO_ATT_X3: the fp32-MFMA attention in every mode)
 O=gpurun_out/r04; mkdir -p $O
-rc=0
-
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_graphs.py -x -q -m gpu -k "attention or tail or fixture or fp16_path or full_size_properties or poisoned or split_precision or release_shape or graph or random_config" > $O/tests_attx3.log 2>&1; rc=$?
+tail -3 $O/tests_attx3.log
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 200 python tools/att_probe.py --x3 > $O/att_x3.txt 2>&1 || { tail -5 $O/att_x3.txt; exit 61; }
 timeout -k 10 200 python tools/att_probe.py > $O/att_f32.txt 2>&1 || { tail -5 $O/att_f32.txt; exit 62; }
+echo x3; grep "B=" $O/att_x3.txt; echo f32; grep "B=" $O/att_f32.txt
 for r in 1 2; do
 timeout -k 10 300 python bench.py --dtype f16 --no-cpu-baseline --no-secondary > $O/b_ax_$r.json 2> $O/b_ax.err || exit 52
 HMV_LIB=build/libhandmv_noax.so timeout -k 10 300 python bench.py --dtype f16 --no-cpu-baseline --no-secondary > $O/b_noax_$r.json 2> $O/b_noax.err || exit 53

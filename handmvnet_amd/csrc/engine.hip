@@ -1802,14 +1802,16 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
     float *X = tokens;
     int Tcur = V * NJ;
     // q/k/v projection of fp32 token rows; in the fp16 / f32x3 modes on the fused split kernels (Loader::linear_x3)
-    auto project = [&](const Layer &L, const float *a, int rows, float *out, int ldc, float *ready_pairs = nullptr) {
+    // pairs_out: the result rows as (hi, lo) fp16 pairs [hi ldc | lo ldc] (the GEMM's pair epilogue; same bytes as fp32 rows) for a consumer
+    // that multiplies on the fp16 matrix cores (attention_x3_kernel)
+    auto project = [&](const Layer &L, const float *a, int rows, float *out, int ldc, float *ready_pairs = nullptr, bool pairs_out = false) {
         if (!L.plane) { R.gemm(L, a, rows, out, ldc, nullptr, 0, ACT_NONE); return; }
         float *pairs = ready_pairs;
         if (!pairs) {
             pairs = R.alloc((size_t)rows * ldt);                           // [hi ldt | lo ldt] halfs per row
             LAUNCH(launch_rows_f32_to_half(a, pairs, (size_t)rows, ldt, 2, s));
         }
-        R.conv(L, pairs, rows, 1, 1, 1, 0, 0, out, ldc, nullptr, 0, ACT_NONE, 1, 1);
+        R.conv(L, pairs, rows, 1, 1, 1, 0, 0, out, ldc, nullptr, 0, ACT_NONE, 1, 1, 0, 0, 0, 0, 0, pairs_out);
         R.release(pairs);
     };
     if (h->lq) {
@@ -1875,17 +1877,19 @@ int run_forward(hmv_engine *h, int B, const float *x, const float *bbox, const f
         const bool cross = (l == half);
         const int Tq = cross ? NJ : Tcur, koff = cross ? NJ : 0, Tk = cross ? Tcur - NJ : Tcur;
         const int rows = B * Tcur, qrows = B * Tq;
+#ifdef HMV_NO_ATT_X3   // A/B builds only (python -m handmvnet_amd.build --variant noax HMV_NO_ATT_X3): the exact-fp32 attention in every mode
+        const int att_x3 = 0;
+#else
+        // fp16-kernel modes: the projection writes q, k, v as (hi, lo) pairs and the attention multiplies on the fp16 matrix cores (by the
+        // arithmetic mode alone: a sample's result never depends on the batch)
+        const int att_x3 = (h16 && a.qkv.plane) ? 1 : 0;
+#endif
         float *qkv = R.alloc((size_t)rows * 3 * INNER);
-        project(a.qkv, X, rows, qkv, 3 * INNER, Xpairs);
+        project(a.qkv, X, rows, qkv, 3 * INNER, Xpairs, att_x3 != 0);
         Xpairs = nullptr;
         float *att = R.alloc((size_t)qrows * INNER);
         // fp16-kernel modes, fused tail: the attention rows leave the kernel as (hi, lo) pairs and to_out is a split-pair GEMM
         const bool tx3 = a.out_x3.plane != 0 && R.ff_fusable(a.out, a.ff1, a.ff2, qrows, ldt, true);
-#ifdef HMV_NO_ATT_X3   // A/B builds only (python -m handmvnet_amd.build --variant noax HMV_NO_ATT_X3): the exact-fp32 attention in every mode
-        const int att_x3 = 0;
-#else
-        const int att_x3 = h16 ? 1 : 0;   // fp16-kernel modes: q, k, v, P as (hi, lo) pairs on the fp16 matrix cores (by the arithmetic mode alone)
-#endif
         if (Tk > 0) LAUNCH(launch_attention(qkv, B, Tcur, Tq, koff, Tk, att, s, tx3 ? 1 : 0, att_x3));
         else LAUNCH(hipMemsetAsync(att, 0, (size_t)qrows * INNER * sizeof(float), s));   // (zero rows are zero pairs)
         R.release(qkv);
@@ -2289,7 +2293,14 @@ int hmv_op_attention_x3(int32_t device, const float *qkv, int32_t B, int32_t T, 
         return HMV_ERR_ARG;
     }
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return HMV_ERR_HIP; }
-    const hipError_t e = launch_attention(qkv, B, T, Tq, koff, Tk, out, static_cast<hipStream_t>(stream), 0, 1);
+    // the kernel takes rows of (hi, lo) fp16 pairs (what the projection GEMMs write in those modes): split the fp32 rows first
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    void *pairs = nullptr;
+    hipError_t e = hipMalloc(&pairs, (size_t)B * T * 3072 * 4);
+    if (e == hipSuccess) e = launch_rows_f32_to_half(qkv, pairs, (size_t)B * T, 3072, 2, s);
+    if (e == hipSuccess) e = launch_attention(static_cast<const float *>(pairs), B, T, Tq, koff, Tk, out, s, 0, 1);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (pairs) (void)hipFree(pairs);
     if (e != hipSuccess) { g_create_err = std::string("attention launch failed: ") + hipGetErrorString(e); return HMV_ERR_HIP; }
     return HMV_OK;
 }

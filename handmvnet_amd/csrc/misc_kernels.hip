@@ -908,10 +908,9 @@ __global__ __launch_bounds__(64 * ATT_WAVES, D == 128 ? HMV_ATT_OCC : 1) void at
 // lo = fp16(x - hi), and three MFMAs per k16 step -- hi.hi + lo.hi + hi.lo, fp32 accumulation: fp32-equivalent (2^-22 per operand) like
 // the q / k / v projections in front of it (gemm_x3.hip) at 8 + 8 instead of 64 + 64 matrix-pipe cycles per 16 channels / keys.  The
 // exact-fp32 kernel spends 41 of its 88 us at cfg-3 in the matrix pipe (tools/att_probe.py).
-//   S^T   A = K rows (the lane's own key row from global memory, split in registers), B = Q block from LDS, split once per workgroup
-//         and stored in operand order: slot j of lane (q, kh) at step u = channel 16 u + 8 (j >> 2) + 4 kh + (j & 3) for BOTH operands
+//   S^T   A = K rows (the lane's own key row from global memory), B = Q block from LDS (staged once per workgroup)
 //   P V   B = P^T straight from the accumulator registers (slot j of step s = register 8 s + j = key 16 s + 8 (j >> 2) + 4 kh + (j & 3)),
-//         A = V^T: the 16 keys of a step sit row-major [key][channel] in a per-wave LDS buffer (split on the way in) and come back
+//         A = V^T: the 16 keys of a step sit row-major [key][channel] in a per-wave LDS buffer and come back
 //         column-major through ds_read_b64_tr_b16 -- lane 4 q + p of a 16-lane group supplies the address of row q, channels 4 p .. 4 p + 3,
 //         lane i receives channel i of the four rows -- two reads per operand (keys 4 kh + 0 .. 3 and 8 + 4 kh + 0 .. 3).  Row stride
 //         320 bytes: the eight 32-byte row pieces of a 32-lane half fall on distinct banks.
@@ -934,46 +933,52 @@ __device__ __forceinline__ void ax_split4(const f32x4 v, f16x4 &hi, f16x4 &lo) {
 }
 __device__ __forceinline__ f16x8 ax_cat(const f16x4 a, const f16x4 b) { return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
-__global__ __launch_bounds__(64 * AX_WAVES, 2) void attention_x3_kernel(const float *__restrict__ q, int q_ld, int q_bstride,
-        const float *__restrict__ k, const float *__restrict__ v, int kv_ld, int T, int Tq, int Tk, int nqb, float *__restrict__ out, int pairs) {
-    constexpr int D = 128, NC = 4, NU = 16;
+// q / k / v arrive as rows of (hi, lo) fp16 pairs [hi | lo] -- what the split-pair projection GEMMs write with their pair epilogue (conv_igemm
+// out_split, gemm_x3k16) -- so every operand is loaded as the MFMAs take it (splitting fp32 rows here cost ~550 of a chunk's ~1 050 vector
+// instructions, six times per key row at cfg-3).  Pointers address the hi plane in halfs, lo_off halfs further the lo plane; a lane's eight
+// slots of step u are the eight consecutive channels 16 u + 8 kh + j for both operands.
+__global__ __launch_bounds__(64 * AX_WAVES, 2) void attention_x3_kernel(const _Float16 *__restrict__ q, int q_ld, int q_bstride,
+        const _Float16 *__restrict__ k, const _Float16 *__restrict__ v, int kv_ld, int lo_off, int T, int Tq, int Tk, int nqb, float *__restrict__ out, int pairs) {
+    constexpr int D = 128, NC = 4;
     extern __shared__ __attribute__((aligned(16))) char ax_smem[];
     const int qblk = blockIdx.x % nqb, bh = blockIdx.x / nqb;
     const int b = bh >> 3, h = bh & 7;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const size_t ld = (size_t)kv_ld;
-    const float *qb = q + (size_t)b * q_bstride * q_ld + h * D;
-    const float *kb = k + (size_t)b * T * ld + h * D, *vb = v + (size_t)b * T * ld + h * D;
+    const _Float16 *qb = q + (size_t)b * q_bstride * q_ld + h * D;
+    const _Float16 *kb = k + (size_t)b * T * ld + h * D, *vb = v + (size_t)b * T * ld + h * D;
     const int nkc = (Tk + 31) >> 5;
     const float scale = 0.08838834764831845f;   // 128 ** -0.5
     _Float16 *sQ = reinterpret_cast<_Float16 *>(ax_smem);                                   // [2][32][AX_QLD]
     _Float16 *sVw = sQ + AX_Q_HALFS + wave * AX_V_HALFS;                                    // [2][16][AX_VLD], this wave's
 
-    f32x4 kf[NU], v0[8];   // the chunk's key rows; 16 of its value rows (16 keys x 128 channels = 8 vectors per lane)
+    f16x8 kh8[8], kl8[8], vh8[4], vl8[4];   // the chunk's key rows (8 steps x (hi, lo)); 16 of its value rows (16 keys x 128 channels = 4 + 4 vectors per lane)
     int kc = wave;
     // (keys >= Tk read the last valid row: their logits are set to -inf and their P to exactly 0 below, so only finiteness matters)
 #define AX_LOAD_K(KC)                                                                                   \
     do {                                                                                                \
-        const float *krow_ = kb + (size_t)min((KC) * 32 + l31, Tk - 1) * ld + 4 * kh;                   \
-        _Pragma("unroll") for (int u = 0; u < NU; ++u) kf[u] = *reinterpret_cast<const f32x4 *>(krow_ + 8 * u); \
-    } while (0)
-#define AX_LOAD_V(KEY0, VR)                                                                             \
-    do {                                                                                                \
-        _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                              \
-            const int k2_ = min((KEY0) + 2 * it + kh, Tk - 1);   /* unit it * 64 + lane = key 2 it + (lane >> 5), channels 4 (lane & 31) .. */ \
-            VR[it] = *reinterpret_cast<const f32x4 *>(vb + (size_t)k2_ * ld + 4 * l31);                 \
+        const _Float16 *krow_ = kb + (size_t)min((KC) * 32 + l31, Tk - 1) * ld + 8 * kh;                \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                 \
+            kh8[u] = *reinterpret_cast<const f16x8 *>(krow_ + 16 * u);                                  \
+            kl8[u] = *reinterpret_cast<const f16x8 *>(krow_ + lo_off + 16 * u);                         \
         }                                                                                               \
     } while (0)
-    // 16 keys -> the wave's LDS buffer as (hi, lo) halfs, row-major
-#define AX_STORE_V(VR)                                                                                  \
+#define AX_LOAD_V(KEY0)                                                                                 \
+    do {                                                                                                \
+        _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                              \
+            const int k2_ = min((KEY0) + 4 * it + (lane >> 4), Tk - 1);   /* unit it * 64 + lane = key 4 it + (lane >> 4), channels 8 (lane & 15) .. */ \
+            vh8[it] = *reinterpret_cast<const f16x8 *>(vb + (size_t)k2_ * ld + 8 * (lane & 15));       \
+            vl8[it] = *reinterpret_cast<const f16x8 *>(vb + (size_t)k2_ * ld + lo_off + 8 * (lane & 15)); \
+        }                                                                                               \
+    } while (0)
+    // 16 keys -> the wave's LDS buffer, row-major
+#define AX_STORE_V()                                                                                    \
     do {                                                                                                \
         __builtin_amdgcn_wave_barrier();                                                                \
-        _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                              \
-            f16x4 hi_, lo_;                                                                             \
-            ax_split4(VR[it], hi_, lo_);                                                                \
-            *reinterpret_cast<f16x4 *>(&sVw[(2 * it + kh) * AX_VLD + 4 * l31]) = hi_;                   \
-            *reinterpret_cast<f16x4 *>(&sVw[(16 + 2 * it + kh) * AX_VLD + 4 * l31]) = lo_;              \
+        _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                              \
+            *reinterpret_cast<f16x8 *>(&sVw[(4 * it + (lane >> 4)) * AX_VLD + 8 * (lane & 15)]) = vh8[it]; \
+            *reinterpret_cast<f16x8 *>(&sVw[(16 + 4 * it + (lane >> 4)) * AX_VLD + 8 * (lane & 15)]) = vl8[it]; \
         }                                                                                               \
         __builtin_amdgcn_wave_barrier();                                                                \
     } while (0)
@@ -995,19 +1000,19 @@ __global__ __launch_bounds__(64 * AX_WAVES, 2) void attention_x3_kernel(const fl
     } while (0)
     if (kc < nkc) {
         AX_LOAD_K(kc);
-        AX_LOAD_V(kc * 32, v0);
+        AX_LOAD_V(kc * 32);
     }
-    // Q block (rows >= Tq are zeros) -> (hi, lo) halfs in operand order, shared by the waves
+    // Q block (rows >= Tq are zeros) -> LDS, shared by the waves: the rows as they are (slot j of step u, half kh = channel 16 u + 8 kh + j)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = it * 256 + tid, r = idx >> 5, c = 4 * (idx & 31), row = qblk * 32 + r;
-        f32x4 qv = {0.f, 0.f, 0.f, 0.f};
-        if (row < Tq) qv = *reinterpret_cast<const f32x4 *>(qb + (size_t)row * q_ld + c);
-        f16x4 hi_, lo_;
-        ax_split4(qv, hi_, lo_);
-        const int pos = (c >> 4) * 16 + ((c >> 2) & 1) * 8 + ((c >> 3) & 1) * 4;   // step, k-half, first or second group of four
-        *reinterpret_cast<f16x4 *>(&sQ[r * AX_QLD + pos]) = hi_;
-        *reinterpret_cast<f16x4 *>(&sQ[(32 + r) * AX_QLD + pos]) = lo_;
+    for (int it = 0; it < 2; ++it) {
+        const int idx = it * 256 + tid, r = idx >> 4, c8 = 8 * (idx & 15), row = qblk * 32 + r;
+        f16x8 qh = {0, 0, 0, 0, 0, 0, 0, 0}, ql = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < Tq) {
+            qh = *reinterpret_cast<const f16x8 *>(qb + (size_t)row * q_ld + c8);
+            ql = *reinterpret_cast<const f16x8 *>(qb + (size_t)row * q_ld + lo_off + c8);
+        }
+        *reinterpret_cast<f16x8 *>(&sQ[r * AX_QLD + c8]) = qh;
+        *reinterpret_cast<f16x8 *>(&sQ[(32 + r) * AX_QLD + c8]) = ql;
     }
     __syncthreads();
 
@@ -1024,10 +1029,7 @@ __global__ __launch_bounds__(64 * AX_WAVES, 2) void attention_x3_kernel(const fl
         for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            f16x4 a0h, a0l, a1h, a1l;
-            ax_split4(kf[2 * u], a0h, a0l);
-            ax_split4(kf[2 * u + 1], a1h, a1l);
-            const f16x8 ah = ax_cat(a0h, a1h), al = ax_cat(a0l, a1l);
+            const f16x8 ah = kh8[u], al = kl8[u];
             const f16x8 bh_ = *reinterpret_cast<const f16x8 *>(&sQ[l31 * AX_QLD + u * 16 + kh * 8]);
             const f16x8 bl_ = *reinterpret_cast<const f16x8 *>(&sQ[(32 + l31) * AX_QLD + u * 16 + kh * 8]);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh_, sacc, 0, 0, 0);
@@ -1064,11 +1066,11 @@ __global__ __launch_bounds__(64 * AX_WAVES, 2) void attention_x3_kernel(const fl
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[c][e] *= alpha;
-        AX_STORE_V(v0);
-        AX_LOAD_V(kc * 32 + 16, v0);          // the second 16 value rows fly under the first 16 keys' products
+        AX_STORE_V();
+        AX_LOAD_V(kc * 32 + 16);              // the second 16 value rows fly under the first 16 keys' products
         AX_PV(0);
-        AX_STORE_V(v0);
-        if (kc + AX_WAVES < nkc) AX_LOAD_V((kc + AX_WAVES) * 32, v0);   // ... and the next chunk's first 16 value rows under the second
+        AX_STORE_V();
+        if (kc + AX_WAVES < nkc) AX_LOAD_V((kc + AX_WAVES) * 32);   // ... and the next chunk's first 16 value rows under the second
         AX_PV(1);
         __builtin_amdgcn_wave_barrier();
     }
@@ -1153,7 +1155,8 @@ static hipError_t launch_attention_any(const float *q, int q_ld, int q_bstride, 
     return launch_attention_w<D, 4>(q, q_ld, q_bstride, k, v, kv_ld, B, T, Tq, Tk, out, s, pairs, nqb);
 }
 hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, int Tk, float *out, hipStream_t s, int pairs, int x3) {
-    if (x3) {   // the fp16-kernel modes: (hi, lo) operands on the fp16 matrix cores (attention_x3_kernel); by the arithmetic mode alone, never by a size
+    if (x3) {   // the fp16-kernel modes: qkv holds rows of (hi, lo) fp16 pairs [hi 3072 | lo 3072] (the projection GEMMs' pair epilogue) and both
+                // products run on the fp16 matrix cores (attention_x3_kernel); by the arithmetic mode alone, never by a size
         if (Tk <= 0 || Tq <= 0 || B <= 0) return hipErrorInvalidValue;
         static bool configured[64] = {};
         int dev = 0;
@@ -1164,8 +1167,9 @@ hipError_t launch_attention(const float *qkv, int B, int T, int Tq, int koff, in
             configured[dev] = true;
         }
         const int nqb = (Tq + 31) >> 5;
-        hipLaunchKernelGGL(attention_x3_kernel, dim3((unsigned)B * 8 * nqb), dim3(64 * AX_WAVES), AX_LDS_BYTES, s, qkv, 3 * 1024, T,
-                           qkv + (size_t)koff * 3072 + 1024, qkv + (size_t)koff * 3072 + 2048, 3 * 1024, T, Tq, Tk, nqb, out, pairs);
+        const _Float16 *ph = reinterpret_cast<const _Float16 *>(qkv);
+        hipLaunchKernelGGL(attention_x3_kernel, dim3((unsigned)B * 8 * nqb), dim3(64 * AX_WAVES), AX_LDS_BYTES, s, ph, 6 * 1024, T,
+                           ph + (size_t)koff * 6144 + 1024, ph + (size_t)koff * 6144 + 2048, 6 * 1024, 3 * 1024, T, Tq, Tk, nqb, out, pairs);
         return hipGetLastError();
     }
     return launch_attention_any<128>(qkv, 3 * 1024, T, qkv + (size_t)koff * 3072 + 1024, qkv + (size_t)koff * 3072 + 2048, 3 * 1024, B, T, Tq, Tk, out, s, pairs);

@@ -241,7 +241,8 @@ int hmv_op_hr_fuse_up(int32_t device, int32_t f16, const float *base, int32_t N,
 int hmv_op_attention(int32_t device, const float *qkv, int32_t B, int32_t T, int32_t Tq, int32_t koff, int32_t Tk, float *out,
                      void *stream);
 /* The same attention as the fp16-kernel modes (HMV_F16, HMV_F32X3) run it: q, k, v, P as fp16 (hi, lo) pairs on the fp16 matrix cores,
- * three products per step, fp32 accumulation and softmax -- fp32-equivalent (2^-22 per operand).  Same arguments. */
+ * three products per step, fp32 accumulation and softmax -- fp32-equivalent (2^-22 per operand).  Same arguments; the fp32 rows are split into
+ * pairs first (in those modes the projection GEMMs write pairs themselves); synchronises the stream. */
 int hmv_op_attention_x3(int32_t device, const float *qkv, int32_t B, int32_t T, int32_t Tq, int32_t koff, int32_t Tk, float *out,
                         void *stream);
 
